@@ -1,0 +1,226 @@
+/*
+ * ydet.h -- C ABI of libydet.so: the MI355X (gfx950) detection-inference hot path.
+ *
+ * The reference project (he13689/yolo) is pure Python and has no FFI of its own; the
+ * operators below are the ones its hot path invokes through torch / numpy / torchvision.
+ * Each entry point names the reference code it stands in for (paths relative to the
+ * reference root).  A binding (ctypes / cffi / pybind) only needs this header.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer unless the comment says "host";
+ *   - activations are NHWC: element (n,h,w,c) of a tensor with leading dimension `ld`
+ *     and channel offset `coff` lives at base[((n*H + h)*W + w)*ld + coff + c]
+ *     (ld/coff let several producers write disjoint channel slices of one buffer, which is
+ *     how torch.cat(dim=1) disappears);
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), returns 0
+ *     on success and a negative ydet_status otherwise; ydet_last_error() gives the text;
+ *   - the library owns no device memory: buffers and workspaces belong to the caller;
+ *   - nothing throws, nothing calls exit().
+ */
+#ifndef YDET_H
+#define YDET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    YDET_OK = 0,
+    YDET_ERR_ARG = -1,      /* bad shape / alignment / enum */
+    YDET_ERR_LAUNCH = -2,   /* hipLaunchKernel or another HIP call failed */
+    YDET_ERR_WORKSPACE = -3 /* workspace too small */
+} ydet_status;
+
+typedef enum { YDET_F32 = 0, YDET_BF16 = 1 } ydet_dtype;
+typedef enum { YDET_ACT_NONE = 0, YDET_ACT_LEAKY = 1, YDET_ACT_SILU = 2 } ydet_act;
+typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 2 } ydet_res_mode;
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* ydet_last_error(void);
+/* ABI version of the library (bumped when a struct below changes). */
+int ydet_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution + folded BatchNorm + activation (+ residual).
+ * Replaces: utils/moduleUtils.py:8-24 (Conv = Conv2d(bias) + BN + LeakyReLU(0.1)),
+ *           yolov5_official/modules.py:24-41 (Conv = Conv2d + BN + SiLU), models/common.py:22-37
+ *           (same with LeakyReLU(0.01)), the bias-only 1x1 prediction convs
+ *           (models/v3tiny.py:54,59; yolov5_official/model.py:42,58), and the residual adds of
+ *           utils/moduleUtils.py:58,88-91 and yolov5_official/modules.py:218.
+ *
+ * y = act(conv(x, w) + bias) [+ res]            res_mode = AFTER_ACT   (x + act(bn(conv)))
+ * y = act(conv(x, w) + bias + res)              res_mode = BEFORE_ACT  (act(x + bn(conv)))
+ *
+ * Weights are pre-packed by the caller as w[cout_pad][kp], row-major, in `in_dtype`, with
+ * k = (kh*KW + kw)*Cin + c, rows >= Cout and columns >= KH*KW*Cin zero.  BatchNorm is folded into
+ * w and bias by the caller.  `bias` has cout_pad fp32 entries (or is NULL).
+ * Requirements: Cin, x_ld, x_coff multiples of 8 (bf16) or 4 (f32); kp a multiple of 32 (bf16) or
+ * 16 (f32); cout_pad a multiple of 128 and >= Cout.  The residual has the output's shape.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* x;
+    const void* w;
+    const float* bias;
+    const void* res;
+    void* y;
+    int32_t N, H, W, Cin;
+    int32_t Cout, KH, KW, stride, pad;
+    int32_t Ho, Wo;
+    int32_t x_ld, x_coff;
+    int32_t y_ld, y_coff;
+    int32_t res_ld, res_coff;
+    int32_t kp, cout_pad;
+    int32_t act;      /* ydet_act */
+    float slope;      /* LeakyReLU negative slope */
+    int32_t res_mode; /* ydet_res_mode */
+    int32_t in_dtype; /* dtype of x, w and res */
+    int32_t out_dtype;/* dtype of y */
+} ydet_conv_desc;
+int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling / resampling / layout operators on NHWC slices.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* x;
+    void* y;
+    int32_t N, H, W, C;     /* input spatial size and channels moved */
+    int32_t x_ld, x_coff;
+    int32_t y_ld, y_coff;
+    int32_t dtype;
+} ydet_slice_desc;
+
+/* MaxPool2d(2, 2): models/basemodel/d19.py:22,27,34,43,53,175-187.  Output H/2 x W/2. */
+int ydet_maxpool2x2_nhwc(const ydet_slice_desc* d, void* stream);
+/* ZeroPad2d((0,1,0,1)) + MaxPool2d(2, stride 1): models/basemodel/d19.py:190-193.  The padded
+ * zeros take part in the max.  Output H x W. */
+int ydet_maxpool2x2s1_zeropad_nhwc(const ydet_slice_desc* d, void* stream);
+/* SPP: MaxPool2d(k, 1, k//2) for k = 5, 9, 13 (-inf padding): utils/moduleUtils.py:63-75,
+ * yolov5_official/modules.py:271-282.  Writes the three pooled maps at channel offsets
+ * y_coff, y_coff + C, y_coff + 2C of y (the un-pooled input is expected to sit in front of
+ * them already, so the concatenation costs nothing). */
+int ydet_spp_nhwc(const ydet_slice_desc* d, void* stream);
+/* nn.Upsample(scale_factor=2): mode 0 nearest (models/v4.py:128,133; yolov5s.yaml head),
+ * mode 1 bilinear with align_corners=True (models/v3tiny.py:55, models/v3spp.py:80-82). */
+int ydet_upsample2x_nhwc(const ydet_slice_desc* d, int mode, void* stream);
+/* Space to depth on NHWC, H x W x C -> H/2 x W/2 x 4C.
+ *   mode 0 (reorg_layer, utils/moduleUtils.py:28-41): out channel (sy*2+sx)*C + c
+ *   mode 1 (Focus slicing, yolov5_official/modules.py:293): out channel q*C + c with
+ *          q <-> (dy,dx) = (0,0),(1,0),(0,1),(1,1) */
+int ydet_space_to_depth_nhwc(const ydet_slice_desc* d, int mode, void* stream);
+/* Channel-slice copy (the torch.cat fallback when a producer could not write in place). */
+int ydet_copy_slice_nhwc(const ydet_slice_desc* d, void* stream);
+
+/* API-edge layout conversion.  x is NCHW [N,C,H,W] of x_dtype (contiguous); y is NHWC with y_ld
+ * channels per pixel in y_dtype; channels C..c_pad-1 of the slice are written as zero.
+ * focus != 0 applies the Focus slicing on the fly (y is then H/2 x W/2 x 4C). */
+int ydet_nchw_to_nhwc(const void* x, void* y, int N, int C, int H, int W, int y_ld, int y_coff,
+                      int c_pad, int x_dtype, int y_dtype, int focus, void* stream);
+/* NHWC slice -> contiguous NCHW (family-A raw head maps, models/v5.py:65-87). */
+int ydet_nhwc_to_nchw(const void* x, void* y, int N, int C, int H, int W, int x_ld, int x_coff,
+                      int x_dtype, int y_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Box decode.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* head; /* NHWC head map [N, ny, nx, ld], channel a*no + o */
+    int32_t ny, nx, ld;
+    float stride;
+    float anchor_wh[2 * 8]; /* pixel anchors (w,h) per anchor, na <= 8 */
+} ydet_v5_level;
+
+/* Detect.forward in eval mode: yolov5_official/model.py:56-81 (grid_transposed = 0) and
+ * models/yolo.py:42-71 (grid_transposed = 1).
+ *   s = sigmoid(raw); xy = (2 s - 0.5 + grid) * stride; wh = (2 s)^2 * anchor; rest = s
+ * out is [N, sum_l na*ny*nx, no] fp32, row = offset(level) + (a*ny + row)*nx + col. */
+int ydet_decode_v5(const ydet_v5_level* levels /* host */, int nl, int N, int na, int no,
+                   int grid_transposed, int head_dtype, float* out, void* stream);
+
+typedef struct {
+    const void* head; /* NHWC head map [N, H, W, ld], channels [A conf | A*nc cls | A*4 box] */
+    int32_t H, W, ld;
+    float anchor_wh[2 * 8]; /* per-anchor (w,h) as the reference stores them for this scale */
+} ydet_fa_level;
+
+/* Head split + decode of the v2/v3/v4 detectors: models/v3tiny.py:88-111,137-147 (and the
+ * identical tails of v2d19/v3spp/v4) + utils/utils.py:46-98.
+ *   conf = sigmoid(ch a); cls = softmax over ch A + a*nc + c; score = cls * conf
+ *   mode 0 ("v2", xywh_to_xxyy):   c = (sigmoid(t_xy) + g) * mult;  wh = exp(t_wh) * anchor * mult
+ *   mode 1 ("v3", xywh_to_xxyyv3): c = (sigmoid(t_xy) + g) * mult;  wh = exp(t_wh) * anchor
+ *   box = clamp((c -/+ wh/2) / input_size, 0, 1); g = (row, col) -- the reference's grid is
+ *   transposed (utils/utils.py:167-169) -- unless grid_transposed = 0.
+ * boxes [N, n, 4], scores [N, n, nc], n = sum_l H*W*A, box index = offset(level) + (row*W+col)*A + a. */
+int ydet_decode_v2v3(const ydet_fa_level* levels /* host */, int nl, int N, int A, int nc, int mode,
+                     float mult, float input_size, int grid_transposed, int head_dtype,
+                     float* boxes, float* scores, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Non-maximum suppression.
+ * ------------------------------------------------------------------------------------------ */
+/* non_max_suppression: yolov5_official/utils.py:113-195 (with torchvision.ops.nms, line 182,
+ * restated as: greedy over descending score, suppress when inter/(a_i + a_j - inter) > iou_thres,
+ * w,h = max(0, .), ties broken by lower candidate index).
+ * pred [N, nboxes, no] fp32 (xywh, obj, nc class scores).  Per image: candidates are boxes with
+ * obj > conf and (multi_label) every class with obj*cls > conf, else the best class; the top
+ * max_nms by score enter the NMS with boxes offset by cls*max_wh (0 if agnostic), all in fp32;
+ * at most max_det survive.  class_mask (device, nc bytes, may be NULL) keeps only classes whose
+ * byte is non-zero (the `classes=` filter, line 165-166).
+ * out_det [N, max_det, 6] = (x1,y1,x2,y2,score,cls) in descending score order, rows >= count zero;
+ * out_count [N] int32.  workspace: ydet_nms_v5_workspace_bytes(N, nboxes, no) bytes.
+ * Limits: max_nms <= 4096, max_det <= max_nms. */
+size_t ydet_nms_v5_workspace_bytes(int N, int nboxes, int no);
+int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
+                const uint8_t* class_mask, float* out_det, int32_t* out_count, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* postprocess + nms: utils/utils.py:101-133 and :15-42.
+ * boxes [N, n, 4], scores [N, n, nc] fp32.  Per image: cls = argmax (first maximum),
+ * score = max, candidates have score >= conf_thresh; per class greedy NMS in descending score
+ * (equal scores: higher box index first, i.e. a stable ascending sort reversed) with
+ * w,h = max(1e-28, .) and survivors ovr <= nms_thresh (NaN suppresses).
+ * out_keep [N, n] uint8 (1 = kept, original box order), out_cls [N, n] int32 (argmax class),
+ * out_score [N, n] fp32 (best score). */
+size_t ydet_nms_perclass_workspace_bytes(int N, int n, int nc);
+int ydet_nms_perclass(const float* boxes, const float* scores, int N, int n, int nc,
+                      float conf_thresh, float nms_thresh, uint8_t* out_keep, int32_t* out_cls,
+                      float* out_score, void* workspace, size_t workspace_bytes, void* stream);
+
+/* box_iou: yolov5_official/utils.py:601-611.  a [na,4], b [nb,4] xyxy fp32 -> iou [na, nb]. */
+int ydet_box_iou(const float* a, int na, const float* b, int nb, float* iou, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch-list executor: one call runs a whole pre-planned forward pass
+ * (the Python loop of Model.forward_once, yolov5_official/model.py:220-234, and the forward()
+ * bodies of models/v2d19.py, v3tiny.py, v3spp.py, v4.py).
+ * ------------------------------------------------------------------------------------------ */
+typedef enum {
+    YDET_OP_CONV = 0,
+    YDET_OP_MAXPOOL2 = 1,
+    YDET_OP_MAXPOOL2S1 = 2,
+    YDET_OP_SPP = 3,
+    YDET_OP_UPSAMPLE = 4,      /* iarg = mode */
+    YDET_OP_SPACE2DEPTH = 5,   /* iarg = mode */
+    YDET_OP_COPY = 6,
+    YDET_OP_NCHW2NHWC = 7,     /* slice: x=src NCHW, C = real channels; iarg = focus, iarg2 = c_pad,
+                                  iarg3 = source dtype */
+    YDET_OP_NHWC2NCHW = 8      /* iarg3 = destination dtype */
+} ydet_op_kind;
+
+typedef struct {
+    int32_t kind;
+    int32_t iarg, iarg2, iarg3;
+    ydet_conv_desc conv;   /* YDET_OP_CONV */
+    ydet_slice_desc slice; /* everything else */
+} ydet_op;
+
+int ydet_run_ops(const ydet_op* ops /* host */, int n_ops, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YDET_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libydet.so (declared in include/ydet.h).
+
+The library is the only compute path of this package on a GPU: if it cannot be loaded the first
+call raises, there is no fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libydet.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
+RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
+(OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
+ OP_NHWC2NCHW) = range(9)
+MAX_ANCHORS = 8
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("x_ld", C.c_int32), ("x_coff", C.c_int32),
+        ("y_ld", C.c_int32), ("y_coff", C.c_int32),
+        ("res_ld", C.c_int32), ("res_coff", C.c_int32),
+        ("kp", C.c_int32), ("cout_pad", C.c_int32),
+        ("act", C.c_int32), ("slope", C.c_float), ("res_mode", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
+    ]
+
+
+class SliceDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("x_ld", C.c_int32), ("x_coff", C.c_int32),
+        ("y_ld", C.c_int32), ("y_coff", C.c_int32),
+        ("dtype", C.c_int32),
+    ]
+
+
+class V5Level(C.Structure):
+    _fields_ = [
+        ("head", C.c_void_p), ("ny", C.c_int32), ("nx", C.c_int32), ("ld", C.c_int32),
+        ("stride", C.c_float), ("anchor_wh", C.c_float * (2 * MAX_ANCHORS)),
+    ]
+
+
+class FALevel(C.Structure):
+    _fields_ = [
+        ("head", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("ld", C.c_int32),
+        ("anchor_wh", C.c_float * (2 * MAX_ANCHORS)),
+    ]
+
+
+class Op(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("iarg", C.c_int32), ("iarg2", C.c_int32), ("iarg3", C.c_int32),
+        ("conv", ConvDesc), ("slice", SliceDesc),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ydet.h declares
+SYMBOLS = {
+    "ydet_last_error": (C.c_char_p, []),
+    "ydet_abi_version": (C.c_int, []),
+    "ydet_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ydet_maxpool2x2_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
+    "ydet_maxpool2x2s1_zeropad_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
+    "ydet_spp_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
+    "ydet_upsample2x_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_int, C.c_void_p]),
+    "ydet_space_to_depth_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_int, C.c_void_p]),
+    "ydet_copy_slice_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
+    "ydet_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
+    "ydet_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "ydet_decode_v5": (C.c_int, [C.POINTER(V5Level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p]),
+    "ydet_decode_v2v3": (C.c_int, [C.POINTER(FALevel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                   C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ydet_nms_v5_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ydet_nms_v5": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_size_t, C.c_void_p]),
+    "ydet_nms_perclass_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ydet_nms_perclass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ydet_box_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ydet_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError if libydet.so is missing or incomplete."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C yolo_amd/csrc` (or __graft_entry__.build()); "
+                "the HIP library is the only GPU path of yolo_amd")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ydet_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libydet {what} failed ({rc}): {msg}")
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

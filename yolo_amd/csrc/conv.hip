@@ -1,0 +1,361 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): Conv2d + folded BatchNorm + LeakyReLU/SiLU
+// (+ residual) on NHWC activations, bf16 or fp32 MFMA with fp32 accumulation.
+//
+// GEMM view:  D[co, m] = sum_k Wp[co, k] * X[m, k]
+//   m  = flattened output pixel (n, ho, wo)             -> the MFMA column (lane & 15)
+//   co = output channel                                  -> the MFMA row
+//   k  = (kh*KW + kw)*Cin + c, gathered on the fly from the NHWC input (never materialised).
+// Channels sit on the MFMA row so that every lane ends up with 4 consecutive output channels of
+// one pixel: the epilogue stores 8 B (bf16) / 16 B (fp32) per lane straight into the NHWC output.
+//
+// Both operands are K-contiguous (packed weights [Cout][K], NHWC input), so one K-step of a tile is
+// a set of 64-byte rows = 4 chunks of 16 B: 32 bf16 or 16 fp32 values.  The same staging code, LDS
+// image and fragment reads serve both dtypes; only the MFMA differs
+// (1 x v_mfma_f32_16x16x32_bf16 or 4 x v_mfma_f32_16x16x4_f32 per fragment pair and K-step).
+//
+// LDS image: row r of a tile at byte r*64, its logical chunk c stored at physical chunk
+// c ^ F[(r>>2)&3], F = {0,2,3,1}: with that permutation the 16 lanes of every ds_read_b128 lane
+// group (rows l&15, chunk l>>4) touch 16 distinct 16-byte bank slots, so fragment reads are
+// conflict-free on 64-byte rows.
+//
+// Pipeline: global -> registers -> LDS, two LDS stages, one barrier per K-step; the global loads of
+// step k+1 are issued before the MFMAs of step k and written to the other stage after them.
+#include "ydet_internal.h"
+
+using namespace ydet;
+
+namespace {
+
+struct ConvArgs {
+    const char* x;
+    const char* w;
+    const float* bias;
+    const char* res;
+    char* y;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int x_ld, x_coff, y_ld, y_coff, res_ld, res_coff;
+    int kp, act, res_mode;
+    float slope;
+    long long M;      // N*Ho*Wo
+    int tiles_n;      // channel tiles
+    int vec_store;    // 4-channel vector stores are legal
+};
+
+__device__ __forceinline__ int chunk_swz(int g) { return (0x78 >> (2 * (g & 3))) & 3; }
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<__bf16> {
+    using type = bf16x8;
+};
+template <>
+struct Frag<float> {
+    using type = f32x4;
+};
+
+__device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// 16 fp32 k-values per step: lane group g = lane>>4 holds k = 4g..4g+3 of its row in both operands,
+// MFMA j consumes element j of every lane, so the four MFMAs together cover all 16 k exactly once.
+__device__ __forceinline__ f32x4 mma(const f32x4& a, const f32x4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ float activate(float v, int act, float slope) {
+    if (act == YDET_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    if (act == YDET_ACT_SILU) return v / (1.0f + __expf(-v));
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const char* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const char* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void load4<__bf16>(const char* p, float (&v)[4]) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+template <typename T>
+__device__ __forceinline__ void store4(char* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(char* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<__bf16>(char* p, const float (&v)[4]) {
+    bf16x4 t;
+    t[0] = (__bf16)v[0]; t[1] = (__bf16)v[1]; t[2] = (__bf16)v[2]; t[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = t;
+}
+
+// BN x BM output tile (channels x pixels) per 256-thread workgroup, WARPS_N x WARPS_M waves.
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool IS1X1>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(WARPS_N * WARPS_M == 4, "four waves per workgroup");
+    constexpr int EPC = 16 / (int)sizeof(TIN);  // elements per 16-byte chunk
+    constexpr int BK = 4 * EPC;                 // K elements per step (64 bytes)
+    constexpr int WN = BN / WARPS_N, WM = BM / WARPS_M;
+    constexpr int FN = WN / 16, FM = WM / 16;
+    constexpr int WL = (BN + 63) / 64, XL = BM / 64;
+    constexpr int STAGE = (BN + BM) * 64;
+    using frag_t = typename Frag<TIN>::type;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WARPS_N, wm = wave / WARPS_N;
+
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const long long tile_m = bid / a.tiles_n;
+    const int n0 = tile_n * BN;
+    const long long m0 = tile_m * BM;
+
+    // ---- staging roles: thread -> (row tid>>2 (+64 i), chunk tid&3) -------------------------------
+    const int ld_row = tid >> 2, ld_ch = tid & 3;
+    const int st_off = ld_row * 64 + ((ld_ch ^ chunk_swz(tid >> 4)) << 4);
+
+    // weight rows: always in bounds (packed weights are padded to cout_pad x kp)
+    const char* wptr[WL];
+#pragma unroll
+    for (int i = 0; i < WL; ++i)
+        wptr[i] = a.w + ((size_t)(n0 + ld_row + 64 * i) * a.kp + ld_ch * EPC) * sizeof(TIN);
+
+    // pixel rows
+    bool xok[XL];
+    int hi0[XL], wi0[XL];
+    const char* xbase[XL];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const long long m = m0 + ld_row + 64 * i;
+        xok[i] = m < a.M;
+        const long long mm = xok[i] ? m : 0;
+        const int n = (int)(mm / HoWo);
+        const int rem = (int)(mm - (long long)n * HoWo);
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+        xbase[i] = a.x + ((size_t)n * a.H * a.W * a.x_ld + a.x_coff) * sizeof(TIN);
+    }
+
+    // running position of this thread's chunk inside the K axis: tap (kh,kw) and channel c
+    int kc = ld_ch * EPC, kh = 0, kw = 0;
+    if (!IS1X1) {
+        while (kc >= a.Cin) {
+            kc -= a.Cin;
+            if (++kw == a.KW) { kw = 0; ++kh; }
+        }
+    }
+
+    uint4 wreg[WL], xreg[XL];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            if (BN >= 64 || ld_row < BN) wreg[i] = *reinterpret_cast<const uint4*>(wptr[i]);
+            wptr[i] += BK * sizeof(TIN);
+        }
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            bool ok;
+            size_t off;
+            if (IS1X1) {
+                ok = xok[i] && kc < a.Cin;
+                off = ((size_t)(hi0[i] * a.W + wi0[i]) * a.x_ld + kc) * sizeof(TIN);
+            } else {
+                const int hi = hi0[i] + kh, wi = wi0[i] + kw;
+                ok = xok[i] && kh < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                off = ((size_t)(hi * a.W + wi) * a.x_ld + kc) * sizeof(TIN);
+            }
+            xreg[i] = ok ? *reinterpret_cast<const uint4*>(xbase[i] + off) : zero4;
+        }
+        // advance to the next K-step
+        kc += BK;
+        if (!IS1X1) {
+            while (kc >= a.Cin) {
+                kc -= a.Cin;
+                if (++kw == a.KW) { kw = 0; ++kh; }
+            }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* ws = smem + stage * STAGE;
+        char* xs = ws + BN * 64;
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            if (BN >= 64 || ld_row < BN) *reinterpret_cast<uint4*>(ws + st_off + i * 64 * 64) = wreg[i];
+#pragma unroll
+        for (int i = 0; i < XL; ++i) *reinterpret_cast<uint4*>(xs + st_off + i * 64 * 64) = xreg[i];
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offset of this lane inside a 16-row group
+    const int fr_off = (lane & 15) * 64 + (((lane >> 4) ^ chunk_swz(lane >> 2)) << 4);
+
+    auto compute = [&](int stage) {
+        const char* ws = smem + stage * STAGE + (wn * WN) * 64 + fr_off;
+        const char* xs = smem + stage * STAGE + BN * 64 + (wm * WM) * 64 + fr_off;
+        frag_t fa[FN], fb[FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) fa[i] = *reinterpret_cast<const frag_t*>(ws + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) fb[j] = *reinterpret_cast<const frag_t*>(xs + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+    };
+
+    const int nk = a.kp / BK;
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) load_tile();
+        compute(kt & 1);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, activation, residual, store -----------------------------------------------
+    const int q = lane >> 4, px = lane & 15;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const long long m = m0 + wm * WM + j * 16 + px;
+        if (m >= a.M) continue;
+        char* yrow = a.y + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
+        const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int co = n0 + wn * WN + i * 16 + q * 4;
+            if (co >= a.Cout) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (a.vec_store) {
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                if (rrow) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
+                if (a.res_mode == YDET_RES_BEFORE_ACT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = activate(v[e] + r[e], a.act, a.slope);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = activate(v[e], a.act, a.slope) + r[e];
+                }
+                store4<TOUT>(yrow + (size_t)co * sizeof(TOUT), v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (co + e >= a.Cout) break;
+                    float r = 0.f;
+                    if (rrow) r = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
+                    float o = a.res_mode == YDET_RES_BEFORE_ACT ? activate(v[e] + r, a.act, a.slope)
+                                                                : activate(v[e], a.act, a.slope) + r;
+                    reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(o);
+                }
+            }
+        }
+    }
+}
+
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
+int launch_tile(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    const long long tiles_m = (a.M + BM - 1) / BM;
+    const long long nblk = tiles_m * a.tiles_n;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(YDET_ERR_ARG, "conv: grid of %lld blocks", nblk);
+    const size_t lds = 2 * (size_t)(BN + BM) * 64;
+    const bool is1x1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
+    if (is1x1)
+        hipLaunchKernelGGL((conv_igemm_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, true>), dim3((unsigned)nblk),
+                           dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
+                           dim3(256), lds, stream, a);
+    YDET_CHECK_LAUNCH("conv_igemm_kernel");
+    return YDET_OK;
+}
+
+template <typename TIN, typename TOUT>
+int launch_dtype(const ConvArgs& a, hipStream_t stream) {
+    if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
+    if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
+    return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
+}
+
+}  // namespace
+
+int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
+    YDET_CHECK_ARG(d != nullptr, "conv: null descriptor");
+    YDET_CHECK_ARG(d->x && d->w && d->y, "conv: null x/w/y pointer");
+    YDET_CHECK_ARG(dtype_ok(d->in_dtype) && dtype_ok(d->out_dtype), "conv: bad dtype %d/%d", d->in_dtype,
+                   d->out_dtype);
+    YDET_CHECK_ARG(!(d->in_dtype == YDET_F32 && d->out_dtype == YDET_BF16), "conv: f32 -> bf16 is not built");
+    const int epc = d->in_dtype == YDET_BF16 ? 8 : 4;
+    const int bk = 4 * epc;
+    YDET_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: empty shape");
+    YDET_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv: bad kernel geometry");
+    YDET_CHECK_ARG(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 &&
+                       d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1 && d->Ho > 0 && d->Wo > 0,
+                   "conv: Ho/Wo (%d,%d) do not match H,W,k,s,p", d->Ho, d->Wo);
+    YDET_CHECK_ARG(d->Cin % epc == 0 && d->x_ld % epc == 0 && d->x_coff % epc == 0,
+                   "conv: Cin/x_ld/x_coff (%d,%d,%d) must be multiples of %d", d->Cin, d->x_ld, d->x_coff, epc);
+    YDET_CHECK_ARG(d->x_coff >= 0 && d->x_coff + d->Cin <= d->x_ld, "conv: input slice exceeds x_ld");
+    YDET_CHECK_ARG(d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld, "conv: output slice exceeds y_ld");
+    YDET_CHECK_ARG(d->kp % bk == 0 && d->kp >= d->KH * d->KW * d->Cin, "conv: kp %d (need multiple of %d, >= %d)",
+                   d->kp, bk, d->KH * d->KW * d->Cin);
+    YDET_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->Cout, "conv: cout_pad %d", d->cout_pad);
+    YDET_CHECK_ARG(d->act >= 0 && d->act <= 2 && d->res_mode >= 0 && d->res_mode <= 2, "conv: bad act/res_mode");
+    YDET_CHECK_ARG((d->res != nullptr) == (d->res_mode != YDET_RES_NONE), "conv: res pointer vs res_mode");
+    YDET_CHECK_ARG(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 15) == 0 &&
+                       ((uintptr_t)d->bias & 15) == 0 && ((uintptr_t)d->res & 15) == 0,
+                   "conv: pointers must be 16-byte aligned");
+    if (d->res) YDET_CHECK_ARG(d->res_coff >= 0 && d->res_coff + d->Cout <= d->res_ld, "conv: residual slice");
+    YDET_CHECK_ARG((long long)d->H * d->W * d->x_ld < (1LL << 31), "conv: one image exceeds 2^31 elements");
+
+    ConvArgs a;
+    a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.res = (const char*)d->res;
+    a.y = (char*)d->y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+    a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
+    a.res_ld = d->res_ld; a.res_coff = d->res_coff;
+    a.kp = d->kp; a.act = d->act; a.res_mode = d->res_mode; a.slope = d->slope;
+    a.M = (long long)d->N * d->Ho * d->Wo;
+    a.tiles_n = 0;
+    a.vec_store = (d->Cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0 &&
+                   (!d->res || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0)))
+                      ? 1
+                      : 0;
+
+    if (d->in_dtype == YDET_BF16)
+        return d->out_dtype == YDET_BF16 ? launch_dtype<__bf16, __bf16>(a, stream)
+                                         : launch_dtype<__bf16, float>(a, stream);
+    return launch_dtype<float, float>(a, stream);
+}
+
+extern "C" int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream) {
+    clear_error();
+    return ydet_launch_conv(d, as_stream(stream));
+}

@@ -1,0 +1,221 @@
+// Box decode kernels (gfx950).  Both are HBM-bound: every head value is read once and every decoded
+// value written once.  Compiled with -ffp-contract=off so that the arithmetic keeps the operation
+// order of the Python expressions it replaces.
+#include "ydet_internal.h"
+
+using namespace ydet;
+
+namespace {
+
+constexpr int kMaxLevels = 4;
+constexpr int kMaxAnchors = 8;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// --------------------------------------------------------------------------------------------------
+// YOLOv5 Detect decode.
+// --------------------------------------------------------------------------------------------------
+struct V5Args {
+    const char* head[kMaxLevels];
+    int ny[kMaxLevels], nx[kMaxLevels], ld[kMaxLevels];
+    int box_off[kMaxLevels + 1];  // first output row of each level; [nl] = rows per image
+    float stride[kMaxLevels];
+    float anchor[kMaxLevels][2 * kMaxAnchors];
+    int nl, N, na, no, transposed;
+    float* out;
+    long long total_boxes;  // N * rows per image
+};
+
+struct BoxDesc {
+    long long src;  // element offset of channel a*no of this box's pixel in its head map
+    int level;
+    float gx, gy, stride, aw, ah;
+};
+
+constexpr int kBoxesPerBlock = 64;
+
+// One workgroup decodes kBoxesPerBlock consecutive output rows (= kBoxesPerBlock*no contiguous
+// floats of the output).  The per-row index arithmetic is done once per row into LDS; the element
+// loop then only needs one division by `no`.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_v5_kernel(const V5Args a) {
+    __shared__ BoxDesc desc[kBoxesPerBlock];
+    const long long row0 = (long long)blockIdx.x * kBoxesPerBlock;
+    const int rows_per_img = a.box_off[a.nl];
+    if (threadIdx.x < kBoxesPerBlock) {
+        const long long r = row0 + threadIdx.x;
+        BoxDesc d;
+        d.level = -1;
+        if (r < a.total_boxes) {
+            const int n = (int)(r / rows_per_img);
+            const int b = (int)(r - (long long)n * rows_per_img);
+            int l = 0;
+            while (l + 1 < a.nl && b >= a.box_off[l + 1]) ++l;
+            const int lb = b - a.box_off[l];
+            const int hw = a.ny[l] * a.nx[l];
+            const int an = lb / hw;
+            const int cell = lb - an * hw;
+            const int row = cell / a.nx[l], col = cell - row * a.nx[l];
+            d.level = l;
+            d.src = ((long long)((long long)n * a.ny[l] + row) * a.nx[l] + col) * a.ld[l] + (long long)an * a.no;
+            d.gx = a.transposed ? (float)row : (float)col;
+            d.gy = a.transposed ? (float)col : (float)row;
+            d.stride = a.stride[l];
+            d.aw = a.anchor[l][2 * an];
+            d.ah = a.anchor[l][2 * an + 1];
+        }
+        desc[threadIdx.x] = d;
+    }
+    __syncthreads();
+    const int nelem = kBoxesPerBlock * a.no;
+    float* out = a.out + row0 * a.no;
+    for (int e = threadIdx.x; e < nelem; e += 256) {
+        const int bl = e / a.no;
+        const int o = e - bl * a.no;
+        const BoxDesc d = desc[bl];
+        if (d.level < 0) break;  // rows past the end: all later e belong to later rows
+        const T* h = reinterpret_cast<const T*>(a.head[d.level]);
+        const float s = sigmoidf_(to_f32(h[d.src + o]));
+        float v = s;
+        if (o < 2) {
+            v = (s * 2.0f - 0.5f + (o == 0 ? d.gx : d.gy)) * d.stride;
+        } else if (o < 4) {
+            const float t = s * 2.0f;
+            v = t * t * (o == 2 ? d.aw : d.ah);
+        }
+        out[e] = v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// v2/v3/v4 head split + decode.
+// --------------------------------------------------------------------------------------------------
+struct FAArgs {
+    const char* head[kMaxLevels];
+    int H[kMaxLevels], W[kMaxLevels], ld[kMaxLevels];
+    int box_off[kMaxLevels + 1];
+    float anchor[kMaxLevels][2 * kMaxAnchors];
+    int nl, N, A, nc, mode, transposed;
+    float mult, input_size;
+    float* boxes;
+    float* scores;
+    long long total;  // N * boxes per image
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_fa_kernel(const FAArgs a) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.total) return;
+    const int per_img = a.box_off[a.nl];
+    const int n = (int)(gid / per_img);
+    const int b = (int)(gid - (long long)n * per_img);
+    int l = 0;
+    while (l + 1 < a.nl && b >= a.box_off[l + 1]) ++l;
+    const int lb = b - a.box_off[l];
+    const int cell = lb / a.A, an = lb - cell * a.A;
+    const int row = cell / a.W[l], col = cell - row * a.W[l];
+    const T* px = reinterpret_cast<const T*>(a.head[l]) + ((size_t)n * a.H[l] * a.W[l] + cell) * a.ld[l];
+
+    const float conf = sigmoidf_(to_f32(px[an]));
+    // softmax over the nc class logits of this anchor, times objectness
+    const T* cl = px + a.A + an * a.nc;
+    float mx = -INFINITY;
+    for (int c = 0; c < a.nc; ++c) mx = fmaxf(mx, to_f32(cl[c]));
+    float sum = 0.f;
+    for (int c = 0; c < a.nc; ++c) sum += expf(to_f32(cl[c]) - mx);
+    float* sc = a.scores + (size_t)gid * a.nc;
+    for (int c = 0; c < a.nc; ++c) sc[c] = expf(to_f32(cl[c]) - mx) / sum * conf;
+
+    const T* t = px + a.A * (1 + a.nc) + an * 4;
+    const float gx = a.transposed ? (float)row : (float)col;
+    const float gy = a.transposed ? (float)col : (float)row;
+    const float aw = a.anchor[l][2 * an], ah = a.anchor[l][2 * an + 1];
+    float cx, cy, w, h;
+    if (a.mode == 0) {  // xywh_to_xxyy: everything scaled by mult
+        cx = (sigmoidf_(to_f32(t[0])) + gx) * a.mult;
+        cy = (sigmoidf_(to_f32(t[1])) + gy) * a.mult;
+        w = expf(to_f32(t[2])) * aw * a.mult;
+        h = expf(to_f32(t[3])) * ah * a.mult;
+    } else {  // xywh_to_xxyyv3: only the centre is scaled
+        cx = (sigmoidf_(to_f32(t[0])) + gx) * a.mult;
+        cy = (sigmoidf_(to_f32(t[1])) + gy) * a.mult;
+        w = expf(to_f32(t[2])) * aw;
+        h = expf(to_f32(t[3])) * ah;
+    }
+    float4 bb;
+    bb.x = fminf(fmaxf((cx - w / 2.0f) / a.input_size, 0.f), 1.f);
+    bb.y = fminf(fmaxf((cy - h / 2.0f) / a.input_size, 0.f), 1.f);
+    bb.z = fminf(fmaxf((cx + w / 2.0f) / a.input_size, 0.f), 1.f);
+    bb.w = fminf(fmaxf((cy + h / 2.0f) / a.input_size, 0.f), 1.f);
+    reinterpret_cast<float4*>(a.boxes)[gid] = bb;
+}
+
+}  // namespace
+
+extern "C" int ydet_decode_v5(const ydet_v5_level* levels, int nl, int N, int na, int no, int grid_transposed,
+                              int head_dtype, float* out, void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(levels && out, "decode_v5: null pointer");
+    YDET_CHECK_ARG(nl >= 1 && nl <= kMaxLevels, "decode_v5: nl=%d (1..%d)", nl, kMaxLevels);
+    YDET_CHECK_ARG(na >= 1 && na <= kMaxAnchors, "decode_v5: na=%d (1..%d)", na, kMaxAnchors);
+    YDET_CHECK_ARG(N > 0 && no >= 5, "decode_v5: N=%d no=%d", N, no);
+    YDET_CHECK_ARG(dtype_ok(head_dtype), "decode_v5: bad dtype");
+    V5Args a;
+    a.nl = nl; a.N = N; a.na = na; a.no = no; a.transposed = grid_transposed ? 1 : 0; a.out = out;
+    long long off = 0;
+    for (int l = 0; l < nl; ++l) {
+        const ydet_v5_level& L = levels[l];
+        YDET_CHECK_ARG(L.head && L.ny > 0 && L.nx > 0 && L.ld >= na * no, "decode_v5: level %d shape", l);
+        a.head[l] = (const char*)L.head; a.ny[l] = L.ny; a.nx[l] = L.nx; a.ld[l] = L.ld; a.stride[l] = L.stride;
+        for (int i = 0; i < 2 * kMaxAnchors; ++i) a.anchor[l][i] = i < 2 * na ? L.anchor_wh[i] : 0.f;
+        a.box_off[l] = (int)off;
+        off += (long long)na * L.ny * L.nx;
+        YDET_CHECK_ARG(off < (1LL << 30), "decode_v5: too many boxes per image");
+    }
+    for (int l = nl; l <= kMaxLevels; ++l) a.box_off[l] = (int)off;
+    a.box_off[nl] = (int)off;
+    a.total_boxes = (long long)N * off;
+    const long long grid = (a.total_boxes + kBoxesPerBlock - 1) / kBoxesPerBlock;
+    YDET_CHECK_ARG(grid > 0 && grid < 0x7fffffffLL, "decode_v5: grid");
+    if (head_dtype == YDET_BF16)
+        hipLaunchKernelGGL(decode_v5_kernel<__bf16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(decode_v5_kernel<float>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    YDET_CHECK_LAUNCH("decode_v5_kernel");
+    return YDET_OK;
+}
+
+extern "C" int ydet_decode_v2v3(const ydet_fa_level* levels, int nl, int N, int A, int nc, int mode, float mult,
+                                float input_size, int grid_transposed, int head_dtype, float* boxes,
+                                float* scores, void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(levels && boxes && scores, "decode_v2v3: null pointer");
+    YDET_CHECK_ARG(nl >= 1 && nl <= kMaxLevels, "decode_v2v3: nl=%d", nl);
+    YDET_CHECK_ARG(A >= 1 && A <= kMaxAnchors && nc >= 1 && N > 0, "decode_v2v3: A=%d nc=%d N=%d", A, nc, N);
+    YDET_CHECK_ARG(mode == 0 || mode == 1, "decode_v2v3: mode");
+    YDET_CHECK_ARG(dtype_ok(head_dtype), "decode_v2v3: bad dtype");
+    YDET_CHECK_ARG(((uintptr_t)boxes & 15) == 0, "decode_v2v3: boxes must be 16-byte aligned");
+    FAArgs a;
+    a.nl = nl; a.N = N; a.A = A; a.nc = nc; a.mode = mode; a.transposed = grid_transposed ? 1 : 0;
+    a.mult = mult; a.input_size = input_size; a.boxes = boxes; a.scores = scores;
+    long long off = 0;
+    for (int l = 0; l < nl; ++l) {
+        const ydet_fa_level& L = levels[l];
+        YDET_CHECK_ARG(L.head && L.H > 0 && L.W > 0 && L.ld >= A * (5 + nc), "decode_v2v3: level %d shape", l);
+        a.head[l] = (const char*)L.head; a.H[l] = L.H; a.W[l] = L.W; a.ld[l] = L.ld;
+        for (int i = 0; i < 2 * kMaxAnchors; ++i) a.anchor[l][i] = i < 2 * A ? L.anchor_wh[i] : 0.f;
+        a.box_off[l] = (int)off;
+        off += (long long)A * L.H * L.W;
+        YDET_CHECK_ARG(off < (1LL << 30), "decode_v2v3: too many boxes per image");
+    }
+    for (int l = nl; l <= kMaxLevels; ++l) a.box_off[l] = (int)off;
+    a.total = (long long)N * off;
+    const long long grid = (a.total + 255) / 256;
+    YDET_CHECK_ARG(grid > 0 && grid < 0x7fffffffLL, "decode_v2v3: grid");
+    if (head_dtype == YDET_BF16)
+        hipLaunchKernelGGL(decode_fa_kernel<__bf16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(decode_fa_kernel<float>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    YDET_CHECK_LAUNCH("decode_fa_kernel");
+    return YDET_OK;
+}

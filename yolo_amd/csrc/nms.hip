@@ -1,0 +1,658 @@
+// Non-maximum suppression for gfx950: candidate filtering, exact top-k pre-filter, rank sort and a
+// chunked greedy NMS whose 64x64 intra-chunk suppression matrix is built with wave-wide ORs.
+// Compiled with -ffp-contract=off: the IoU expressions must round exactly like the scalar
+// CPU code they replace (inter / (area_i + area_j - inter), no fused multiply-add).
+//
+// Shared machinery
+//   order key  : 64-bit, unique per candidate: (orderable(score) << 32) | tie, so "greater key" is
+//                a strict total order; sorting is a rank count (#keys greater than mine).
+//   greedy NMS : sorted boxes are processed in chunks of 64.  Phase A builds the chunk's 64x64
+//                "i suppresses j" matrix in parallel; phase B walks the 64 rows serially (one
+//                lane) against the bitset of already-removed boxes; phase C applies the chunk's
+//                kept boxes to every later box in parallel.
+#include "ydet_internal.h"
+
+using namespace ydet;
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline unsigned f2key_host(float f) {
+    union { float f; unsigned u; } cv;
+    cv.f = f;
+    const unsigned u = cv.u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// torchvision-style overlap test: w,h = max(0, .), suppress when ovr > thr.
+// numpy-style (utils/utils.py nms): w,h = max(1e-28, .), survive when ovr <= thr (NaN suppresses).
+template <bool EPS_LE>
+__device__ __forceinline__ bool suppresses(const float4& bi, float ai, const float4& bj, float aj, float thr) {
+    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+    if (EPS_LE) {
+        const float w = fmaxf(1e-28f, xx2 - xx1), h = fmaxf(1e-28f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / (ai + aj - inter);
+        return !(ovr <= thr);
+    } else {
+        const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+        const float inter = w * h;
+        const float ovr = inter / (ai + aj - inter);
+        return ovr > thr;
+    }
+}
+__device__ __forceinline__ float box_area(const float4& b) { return (b.z - b.x) * (b.w - b.y); }
+
+struct NmsShared {
+    float4 cbox[64];
+    float carea[64];
+    u64 rowmask[64];
+    u64 kept_word;
+};
+
+// Greedy NMS over `ns` boxes already sorted by descending priority.  load(s) returns box s.
+// removed / kept: LDS bitsets of (ns+63)/64 words, zeroed here.  256 threads.
+template <bool EPS_LE, typename LoadBox>
+__device__ void greedy_nms_block(int ns, float thr, LoadBox load, NmsShared& sh, u64* removed, u64* kept) {
+    const int tid = threadIdx.x;
+    const int nwords = (ns + 63) >> 6;
+    for (int w = tid; w < nwords; w += 256) { removed[w] = 0; kept[w] = 0; }
+    __syncthreads();
+    for (int c = 0; c < nwords; ++c) {
+        const int base = c << 6;
+        const int cn = min(64, ns - base);
+        if (tid < 64) {
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < cn) b = load(base + tid);
+            sh.cbox[tid] = b;
+            sh.carea[tid] = box_area(b);
+        }
+        __syncthreads();
+        // phase A: thread (i = tid>>2, part = tid&3) tests j = part*16 .. part*16+15, j > i
+        {
+            const int i = tid >> 2, part = tid & 3;
+            u64 bits = 0;
+            if (i < cn) {
+                const float4 bi = sh.cbox[i];
+                const float ai = sh.carea[i];
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = part * 16 + jj;
+                    if (j > i && j < cn && suppresses<EPS_LE>(bi, ai, sh.cbox[j], sh.carea[j], thr))
+                        bits |= 1ull << j;
+                }
+            }
+            bits |= __shfl_xor(bits, 1);
+            bits |= __shfl_xor(bits, 2);
+            if (part == 0) sh.rowmask[i] = bits;
+        }
+        __syncthreads();
+        // phase B: serial walk over the chunk
+        if (tid == 0) {
+            u64 rem = removed[c], kp = 0;
+            for (int i = 0; i < cn; ++i) {
+                if (!((rem >> i) & 1ull)) {
+                    kp |= 1ull << i;
+                    rem |= sh.rowmask[i];
+                }
+            }
+            kept[c] = kp;
+            sh.kept_word = kp;
+        }
+        __syncthreads();
+        // phase C: kept boxes of this chunk against every later box
+        const u64 kp = sh.kept_word;
+        if (kp) {
+            for (int j = base + 64 + tid; j < ns; j += 256) {
+                if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
+                const float4 bj = load(j);
+                const float aj = box_area(bj);
+                u64 m = kp;
+                while (m) {
+                    const int i = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (suppresses<EPS_LE>(sh.cbox[i], sh.carea[i], bj, aj, thr)) {
+                        atomicOr(&removed[j >> 6], 1ull << (j & 63));
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ==================================================================================================
+// YOLOv5 non_max_suppression
+// ==================================================================================================
+constexpr int kHistBins = 2048;
+constexpr int kListCap = 4096;   // candidates kept for the final sort (>= max_nms)
+constexpr int kMaxNms = 4096;
+constexpr int kTileFloats = 8192;  // LDS staging tile of prediction rows
+
+struct V5Meta {  // per image, 16 words
+    unsigned total;       // candidates above conf
+    unsigned thr_bin;     // lowest histogram bin that enters the list
+    unsigned list_count;  // entries appended to the list
+    unsigned overflow;    // list would exceed kListCap: exact select path
+    unsigned ns;          // sorted candidates entering the NMS
+    unsigned pad[11];
+};
+
+struct V5Args {
+    const float* pred;
+    int N, nboxes, no, nc, rows_per_block;
+    float conf, iou;
+    int multi, agnostic, max_nms, max_det;
+    float max_wh;
+    const uint8_t* class_mask;
+    unsigned base16;  // (orderable(conf) >> 16)
+    // workspace
+    unsigned* hist;   // [N][kHistBins]
+    V5Meta* meta;     // [N]
+    u64* list;        // [N][kListCap]
+    u64* sorted;      // [N][kMaxNms]
+    float4* sbox;     // [N][kMaxNms]  offset boxes in sorted order
+    float* out_det;
+    int32_t* out_count;
+};
+
+__device__ __forceinline__ unsigned score_bin(float s, unsigned base16) {
+    const unsigned b = (f2key(s) >> 16) - base16;
+    return b > (unsigned)(kHistBins - 1) ? (unsigned)(kHistBins - 1) : b;
+}
+
+// Stages rows [row0, row0+rows) of one image into LDS and calls visit(candidate index, score) for
+// every candidate: yolov5_official/utils.py:122 (obj > conf), :151 (cls *= obj), :157-162.
+template <typename F>
+__device__ __forceinline__ void v5_visit(const V5Args& a, const float* img, int row0, int rows, float* tile, F visit) {
+    const int nelem = rows * a.no;
+    const float* src = img + (size_t)row0 * a.no;
+    for (int e = threadIdx.x; e < nelem; e += blockDim.x) tile[e] = src[e];
+    __syncthreads();
+    if (a.multi) {
+        for (int e = threadIdx.x; e < nelem; e += blockDim.x) {
+            const int r = e / a.no, o = e - r * a.no;
+            if (o < 5) continue;
+            const float obj = tile[r * a.no + 4];
+            if (!(obj > a.conf)) continue;
+            const float s = tile[e] * obj;
+            if (!(s > a.conf)) continue;
+            if (a.class_mask && !a.class_mask[o - 5]) continue;
+            visit((unsigned)((row0 + r) * a.nc + (o - 5)), s);
+        }
+    } else {
+        for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+            const float* p = tile + r * a.no;
+            const float obj = p[4];
+            if (!(obj > a.conf)) continue;
+            float best = p[5] * obj;
+            int bj = 0;
+            for (int j = 1; j < a.nc; ++j) {
+                const float v = p[5 + j] * obj;
+                if (v > best) { best = v; bj = j; }
+            }
+            if (!(best > a.conf)) continue;
+            if (a.class_mask && !a.class_mask[bj]) continue;
+            visit((unsigned)((row0 + r) * a.nc + bj), best);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void v5_hist_kernel(const V5Args a) {
+    __shared__ float tile[kTileFloats];
+    __shared__ unsigned lhist[kHistBins];
+    const int img = blockIdx.y;
+    const int row0 = blockIdx.x * a.rows_per_block;
+    const int rows = min(a.rows_per_block, a.nboxes - row0);
+    for (int i = threadIdx.x; i < kHistBins; i += 256) lhist[i] = 0;
+    __syncthreads();
+    const unsigned base16 = a.base16;
+    v5_visit(a, a.pred + (size_t)img * a.nboxes * a.no, row0, rows, tile,
+             [&](unsigned, float s) { atomicAdd(&lhist[score_bin(s, base16)], 1u); });
+    unsigned* gh = a.hist + (size_t)img * kHistBins;
+    for (int i = threadIdx.x; i < kHistBins; i += 256) {
+        const unsigned v = lhist[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// One workgroup per image: lowest bin b with sum_{i>=b} hist[i] >= max_nms (b = 0 if the total is
+// smaller), i.e. every candidate of the top max_nms lies in bins >= b.
+__global__ __launch_bounds__(256) void v5_select_kernel(const V5Args a) {
+    __shared__ unsigned part[256];
+    const int img = blockIdx.x;
+    const unsigned* gh = a.hist + (size_t)img * kHistBins;
+    unsigned loc[8], s = 0;
+    for (int i = 0; i < 8; ++i) { loc[i] = gh[threadIdx.x * 8 + i]; s += loc[i]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int i = 0; i < 256; ++i) total += part[i];
+        unsigned thr_bin = 0, in_list = total;
+        if (total > (unsigned)a.max_nms) {
+            unsigned acc = 0;
+            int t = 255;
+            for (; t >= 0; --t) {
+                if (acc + part[t] >= (unsigned)a.max_nms) break;
+                acc += part[t];
+            }
+            int b = t * 8 + 7;
+            for (;; --b) {
+                acc += gh[b];
+                if (acc >= (unsigned)a.max_nms || b == t * 8) break;
+            }
+            thr_bin = (unsigned)b;
+            in_list = acc;
+        }
+        V5Meta& m = a.meta[img];
+        m.total = total;
+        m.thr_bin = thr_bin;
+        m.list_count = 0;
+        m.overflow = in_list > (unsigned)kListCap ? 1u : 0u;
+        m.ns = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void v5_collect_kernel(const V5Args a) {
+    __shared__ float tile[kTileFloats];
+    const int img = blockIdx.y;
+    V5Meta* m = a.meta + img;
+    if (m->overflow || m->total == 0) return;
+    const int row0 = blockIdx.x * a.rows_per_block;
+    const int rows = min(a.rows_per_block, a.nboxes - row0);
+    const unsigned base16 = a.base16, thr_bin = m->thr_bin;
+    u64* list = a.list + (size_t)img * kListCap;
+    v5_visit(a, a.pred + (size_t)img * a.nboxes * a.no, row0, rows, tile, [&](unsigned idx, float s) {
+        if (score_bin(s, base16) >= thr_bin) {
+            const unsigned pos = atomicAdd(&m->list_count, 1u);
+            if (pos < (unsigned)kListCap) list[pos] = ((u64)f2key(s) << 32) | (u64)(0xFFFFFFFFu - idx);
+        }
+    });
+}
+
+// Exact path for images whose threshold bin holds more than kListCap candidates (heavy score ties):
+// byte-wise radix select of the max_nms-th largest 64-bit key, then a collect of all keys >= it.
+// One workgroup per image re-reads the image once per digit; it runs only when flagged.
+__global__ __launch_bounds__(256) void v5_exact_select_kernel(const V5Args a) {
+    __shared__ float tile[kTileFloats];
+    __shared__ unsigned dh[256];
+    __shared__ u64 s_prefix, s_mask;
+    __shared__ unsigned s_remaining, s_count;
+    const int img = blockIdx.x;
+    V5Meta* m = a.meta + img;
+    if (!m->overflow) return;
+    const float* pimg = a.pred + (size_t)img * a.nboxes * a.no;
+    if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_remaining = (unsigned)a.max_nms; s_count = 0; }
+    __syncthreads();
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += 256) dh[i] = 0;
+        __syncthreads();
+        const u64 prefix = s_prefix, mask = s_mask;
+        for (int row0 = 0; row0 < a.nboxes; row0 += a.rows_per_block) {
+            const int rows = min(a.rows_per_block, a.nboxes - row0);
+            v5_visit(a, pimg, row0, rows, tile, [&](unsigned idx, float s) {
+                const u64 key = ((u64)f2key(s) << 32) | (u64)(0xFFFFFFFFu - idx);
+                if ((key & mask) == prefix) atomicAdd(&dh[(unsigned)(key >> shift) & 255u], 1u);
+            });
+        }
+        if (threadIdx.x == 0) {
+            unsigned acc = 0, rem = s_remaining;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (acc + dh[d] >= rem) break;
+                acc += dh[d];
+            }
+            s_remaining = rem - acc;
+            s_prefix = prefix | ((u64)d << shift);
+            s_mask = mask | (0xFFull << shift);
+        }
+        __syncthreads();
+    }
+    const u64 kth = s_prefix;
+    u64* list = a.list + (size_t)img * kListCap;
+    for (int row0 = 0; row0 < a.nboxes; row0 += a.rows_per_block) {
+        const int rows = min(a.rows_per_block, a.nboxes - row0);
+        v5_visit(a, pimg, row0, rows, tile, [&](unsigned idx, float s) {
+            const u64 key = ((u64)f2key(s) << 32) | (u64)(0xFFFFFFFFu - idx);
+            if (key >= kth) {
+                const unsigned pos = atomicAdd(&s_count, 1u);
+                if (pos < (unsigned)kListCap) list[pos] = key;
+            }
+        });
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) m->list_count = s_count;
+}
+
+// Rank sort of the candidate list (descending key), keep the first max_nms, and gather their boxes:
+// xywh -> xyxy (yolov5_official/utils.py:591-598) plus the class offset cls*max_wh in fp32 (:180-181).
+__global__ __launch_bounds__(256) void v5_rank_kernel(const V5Args a) {
+    __shared__ u64 keys[kListCap];
+    const int img = blockIdx.x;
+    V5Meta* m = a.meta + img;
+    const int n = (int)min(m->list_count, (unsigned)kListCap);
+    const u64* list = a.list + (size_t)img * kListCap;
+    for (int i = threadIdx.x; i < n; i += 256) keys[i] = list[i];
+    __syncthreads();
+    const int ns = min(n, a.max_nms);
+    u64* sorted = a.sorted + (size_t)img * kMaxNms;
+    float4* sbox = a.sbox + (size_t)img * kMaxNms;
+    const float* pimg = a.pred + (size_t)img * a.nboxes * a.no;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const u64 k = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += keys[j] > k ? 1 : 0;
+        if (rank < ns) {
+            sorted[rank] = k;
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+            const unsigned box = idx / (unsigned)a.nc, cls = idx - box * (unsigned)a.nc;
+            const float* p = pimg + (size_t)box * a.no;
+            const float cx = p[0], cy = p[1], w = p[2], h = p[3];
+            const float c = a.agnostic ? 0.f : (float)cls * a.max_wh;
+            float4 b;
+            b.x = (cx - w / 2.f) + c;
+            b.y = (cy - h / 2.f) + c;
+            b.z = (cx + w / 2.f) + c;
+            b.w = (cy + h / 2.f) + c;
+            sbox[rank] = b;
+        }
+    }
+    if (threadIdx.x == 0) m->ns = (unsigned)ns;
+}
+
+__global__ __launch_bounds__(256) void v5_nms_kernel(const V5Args a) {
+    __shared__ NmsShared sh;
+    __shared__ u64 removed[kMaxNms / 64], kept[kMaxNms / 64];
+    __shared__ int wbase[kMaxNms / 64 + 1];
+    const int img = blockIdx.x;
+    const V5Meta* m = a.meta + img;
+    const int ns = (int)m->ns;
+    const float4* sbox = a.sbox + (size_t)img * kMaxNms;
+    float* out = a.out_det + (size_t)img * a.max_det * 6;
+    int count = 0;
+    if (ns > 0) {
+        greedy_nms_block<false>(ns, a.iou, [&](int s) { return sbox[s]; }, sh, removed, kept);
+        const int nwords = (ns + 63) >> 6;
+        if (threadIdx.x == 0) {
+            int acc = 0;
+            for (int w = 0; w < nwords; ++w) { wbase[w] = acc; acc += __popcll(kept[w]); }
+            wbase[nwords] = acc;
+        }
+        __syncthreads();
+        count = min(wbase[nwords], a.max_det);
+        const u64* sorted = a.sorted + (size_t)img * kMaxNms;
+        const float* pimg = a.pred + (size_t)img * a.nboxes * a.no;
+        for (int s = threadIdx.x; s < ns; s += 256) {
+            const u64 kw = kept[s >> 6];
+            if (!((kw >> (s & 63)) & 1ull)) continue;
+            const int pos = wbase[s >> 6] + __popcll(kw & ((1ull << (s & 63)) - 1ull));
+            if (pos >= a.max_det) continue;
+            const u64 k = sorted[s];
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+            const unsigned box = idx / (unsigned)a.nc, cls = idx - box * (unsigned)a.nc;
+            const float* p = pimg + (size_t)box * a.no;
+            const float cx = p[0], cy = p[1], w = p[2], h = p[3];
+            float* o = out + (size_t)pos * 6;
+            o[0] = cx - w / 2.f;
+            o[1] = cy - h / 2.f;
+            o[2] = cx + w / 2.f;
+            o[3] = cy + h / 2.f;
+            o[4] = p[5 + cls] * p[4];
+            o[5] = (float)cls;
+        }
+    }
+    for (int e = count * 6 + threadIdx.x; e < a.max_det * 6; e += 256) out[e] = 0.f;
+    if (threadIdx.x == 0) a.out_count[img] = count;
+}
+
+size_t v5_ws_layout(int N, size_t* o_hist, size_t* o_meta, size_t* o_list, size_t* o_sorted, size_t* o_sbox) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
+    const size_t h = take((size_t)N * kHistBins * sizeof(unsigned));
+    const size_t m = take((size_t)N * sizeof(V5Meta));
+    const size_t l = take((size_t)N * kListCap * sizeof(u64));
+    const size_t s = take((size_t)N * kMaxNms * sizeof(u64));
+    const size_t b = take((size_t)N * kMaxNms * sizeof(float4));
+    if (o_hist) { *o_hist = h; *o_meta = m; *o_list = l; *o_sorted = s; *o_sbox = b; }
+    return off;
+}
+
+// ==================================================================================================
+// Per-class NMS of the v2/v3/v4 detectors (utils/utils.py postprocess + nms)
+// ==================================================================================================
+struct FAArgs {
+    const float* boxes;   // [N][n][4]
+    const float* scores;  // [N][n][nc]
+    int N, n, nc;
+    float conf, thr;
+    uint8_t* keep;        // [N][n]
+    int32_t* cls;         // [N][n]
+    float* best;          // [N][n]
+    // workspace
+    unsigned* count;      // [N][nc]
+    unsigned* cursor;     // [N][nc]
+    unsigned* seg;        // [N][n]  box indices grouped by class
+    unsigned* sorted;     // [N][n]  same, sorted by descending score inside each class
+};
+
+// argmax class (first maximum), threshold, per-class population count.
+__global__ __launch_bounds__(256) void fa_score_kernel(const FAArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)a.N * a.n) return;
+    const int img = (int)(gid / a.n);
+    const float* s = a.scores + (size_t)gid * a.nc;
+    float best = s[0];
+    int bj = 0;
+    for (int j = 1; j < a.nc; ++j) {
+        const float v = s[j];
+        if (v > best) { best = v; bj = j; }
+    }
+    a.cls[gid] = bj;
+    a.best[gid] = best;
+    a.keep[gid] = 0;
+    if (best >= a.conf) atomicAdd(&a.count[(size_t)img * a.nc + bj], 1u);
+}
+
+__device__ __forceinline__ unsigned fa_class_offset(const unsigned* count, int cls) {
+    unsigned off = 0;
+    for (int c = 0; c < cls; ++c) off += count[c];
+    return off;
+}
+
+__global__ __launch_bounds__(256) void fa_scatter_kernel(const FAArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)a.N * a.n) return;
+    if (!(a.best[gid] >= a.conf)) return;
+    const int img = (int)(gid / a.n);
+    const unsigned box = (unsigned)(gid - (long long)img * a.n);
+    const int c = a.cls[gid];
+    const unsigned pos = fa_class_offset(a.count + (size_t)img * a.nc, c) +
+                         atomicAdd(&a.cursor[(size_t)img * a.nc + c], 1u);
+    a.seg[(size_t)img * a.n + pos] = box;
+}
+
+// grid (chunk, class, image): rank of each member inside its class segment.
+// Order: descending score; equal scores: higher box index first (ascending stable sort, reversed).
+__global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
+    __shared__ u64 tk[256];
+    const int img = blockIdx.z, c = blockIdx.y;
+    const unsigned* count = a.count + (size_t)img * a.nc;
+    const unsigned cnt = count[c];
+    const unsigned m = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= cnt) return;
+    const unsigned off = fa_class_offset(count, c);
+    const unsigned* seg = a.seg + (size_t)img * a.n + off;
+    const float* best = a.best + (size_t)img * a.n;
+    u64 mykey = 0;
+    unsigned mybox = 0;
+    if (m < cnt) {
+        mybox = seg[m];
+        mykey = ((u64)f2key(best[mybox]) << 32) | mybox;
+    }
+    unsigned rank = 0;
+    for (unsigned t0 = 0; t0 < cnt; t0 += 256) {
+        const unsigned j = t0 + threadIdx.x;
+        __syncthreads();
+        if (j < cnt) {
+            const unsigned b = seg[j];
+            tk[threadIdx.x] = ((u64)f2key(best[b]) << 32) | b;
+        }
+        __syncthreads();
+        const unsigned lim = min(256u, cnt - t0);
+        for (unsigned q = 0; q < lim; ++q) rank += tk[q] > mykey ? 1u : 0u;
+    }
+    if (m < cnt) a.sorted[(size_t)img * a.n + off + rank] = mybox;
+}
+
+constexpr int kFaMaxWords = 2048;  // up to 131072 boxes per class segment
+
+__global__ __launch_bounds__(256) void fa_nms_kernel(const FAArgs a) {
+    __shared__ NmsShared sh;
+    __shared__ u64 removed[kFaMaxWords], kept[kFaMaxWords];
+    const int img = blockIdx.y, c = blockIdx.x;
+    const unsigned* count = a.count + (size_t)img * a.nc;
+    const int cnt = (int)count[c];
+    if (cnt == 0) return;
+    const unsigned off = fa_class_offset(count, c);
+    const unsigned* sorted = a.sorted + (size_t)img * a.n + off;
+    const float4* boxes = reinterpret_cast<const float4*>(a.boxes) + (size_t)img * a.n;
+    greedy_nms_block<true>(cnt, a.thr, [&](int s) { return boxes[sorted[s]]; }, sh, removed, kept);
+    uint8_t* keep = a.keep + (size_t)img * a.n;
+    for (int s = threadIdx.x; s < cnt; s += 256)
+        if ((kept[s >> 6] >> (s & 63)) & 1ull) keep[sorted[s]] = 1;
+}
+
+size_t fa_ws_layout(int N, int n, int nc, size_t* o_count, size_t* o_cursor, size_t* o_seg, size_t* o_sorted) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
+    const size_t c0 = take((size_t)N * nc * sizeof(unsigned));
+    const size_t c1 = take((size_t)N * nc * sizeof(unsigned));
+    const size_t sg = take((size_t)N * n * sizeof(unsigned));
+    const size_t so = take((size_t)N * n * sizeof(unsigned));
+    if (o_count) { *o_count = c0; *o_cursor = c1; *o_seg = sg; *o_sorted = so; }
+    return off;
+}
+
+// box_iou: yolov5_official/utils.py:601-611 (clamp(0), no epsilon)
+__global__ void box_iou_kernel(const float4* a, int na, const float4* b, int nb, float* out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)na * nb) return;
+    const int i = (int)(gid / nb), j = (int)(gid - (long long)i * nb);
+    const float4 p = a[i], q = b[j];
+    const float a1 = (p.z - p.x) * (p.w - p.y), a2 = (q.z - q.x) * (q.w - q.y);
+    const float w = fmaxf(fminf(p.z, q.z) - fmaxf(p.x, q.x), 0.f);
+    const float h = fmaxf(fminf(p.w, q.w) - fmaxf(p.y, q.y), 0.f);
+    const float inter = w * h;
+    out[gid] = inter / (a1 + a2 - inter);
+}
+
+}  // namespace
+
+extern "C" size_t ydet_nms_v5_workspace_bytes(int N, int nboxes, int no) {
+    (void)nboxes; (void)no;
+    if (N <= 0) return 0;
+    return v5_ws_layout(N, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                           int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
+                           const uint8_t* class_mask, float* out_det, int32_t* out_count, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(pred && out_det && out_count && workspace, "nms_v5: null pointer");
+    YDET_CHECK_ARG(N > 0 && nboxes > 0 && no >= 6, "nms_v5: N=%d nboxes=%d no=%d", N, nboxes, no);
+    YDET_CHECK_ARG(no <= kTileFloats, "nms_v5: no=%d exceeds %d", no, kTileFloats);
+    YDET_CHECK_ARG(max_nms >= 1 && max_nms <= kMaxNms, "nms_v5: max_nms=%d (1..%d)", max_nms, kMaxNms);
+    YDET_CHECK_ARG(max_det >= 1 && max_det <= max_nms, "nms_v5: max_det=%d (1..max_nms)", max_det);
+    const int nc = no - 5;
+    YDET_CHECK_ARG((long long)nboxes * nc < 0xFFFFFFFFLL, "nms_v5: nboxes*nc does not fit 32 bits");
+    YDET_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "nms_v5: workspace must be 256-byte aligned");
+    size_t oh, om, ol, os, ob;
+    const size_t need = v5_ws_layout(N, &oh, &om, &ol, &os, &ob);
+    if (workspace_bytes < need) return fail(YDET_ERR_WORKSPACE, "nms_v5: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    char* ws = (char*)workspace;
+    V5Args a;
+    a.pred = pred; a.N = N; a.nboxes = nboxes; a.no = no; a.nc = nc;
+    a.rows_per_block = kTileFloats / no;
+    if (a.rows_per_block > 128) a.rows_per_block = 128;
+    a.conf = conf_thres; a.iou = iou_thres;
+    a.multi = (multi_label && nc > 1) ? 1 : 0;
+    a.agnostic = agnostic ? 1 : 0;
+    a.max_nms = max_nms; a.max_det = max_det; a.max_wh = max_wh; a.class_mask = class_mask;
+    a.base16 = f2key_host(conf_thres) >> 16;
+    a.hist = (unsigned*)(ws + oh); a.meta = (V5Meta*)(ws + om); a.list = (u64*)(ws + ol);
+    a.sorted = (u64*)(ws + os); a.sbox = (float4*)(ws + ob);
+    a.out_det = out_det; a.out_count = out_count;
+    if (hipMemsetAsync(ws + oh, 0, om + (size_t)N * sizeof(V5Meta) - oh, s) != hipSuccess)
+        return fail(YDET_ERR_LAUNCH, "nms_v5: hipMemsetAsync failed");
+    const dim3 grid2((unsigned)((nboxes + a.rows_per_block - 1) / a.rows_per_block), (unsigned)N);
+    YDET_CHECK_ARG(N <= 65535, "nms_v5: N=%d exceeds 65535", N);
+    hipLaunchKernelGGL(v5_hist_kernel, grid2, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_select_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_collect_kernel, grid2, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_exact_select_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_rank_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_nms_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    YDET_CHECK_LAUNCH("nms_v5 kernels");
+    return YDET_OK;
+}
+
+extern "C" size_t ydet_nms_perclass_workspace_bytes(int N, int n, int nc) {
+    if (N <= 0 || n <= 0 || nc <= 0) return 0;
+    return fa_ws_layout(N, n, nc, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int ydet_nms_perclass(const float* boxes, const float* scores, int N, int n, int nc, float conf_thresh,
+                                 float nms_thresh, uint8_t* out_keep, int32_t* out_cls, float* out_score,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(boxes && scores && out_keep && out_cls && out_score && workspace, "nms_perclass: null pointer");
+    YDET_CHECK_ARG(N > 0 && n > 0 && nc > 0, "nms_perclass: N=%d n=%d nc=%d", N, n, nc);
+    YDET_CHECK_ARG(n <= kFaMaxWords * 64, "nms_perclass: n=%d exceeds %d", n, kFaMaxWords * 64);
+    YDET_CHECK_ARG(N <= 65535 && nc <= 65535, "nms_perclass: N or nc exceeds 65535");
+    YDET_CHECK_ARG(((uintptr_t)boxes & 15) == 0, "nms_perclass: boxes must be 16-byte aligned");
+    YDET_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "nms_perclass: workspace must be 256-byte aligned");
+    size_t oc, ou, og, os;
+    const size_t need = fa_ws_layout(N, n, nc, &oc, &ou, &og, &os);
+    if (workspace_bytes < need)
+        return fail(YDET_ERR_WORKSPACE, "nms_perclass: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    char* ws = (char*)workspace;
+    FAArgs a;
+    a.boxes = boxes; a.scores = scores; a.N = N; a.n = n; a.nc = nc; a.conf = conf_thresh; a.thr = nms_thresh;
+    a.keep = out_keep; a.cls = out_cls; a.best = out_score;
+    a.count = (unsigned*)(ws + oc); a.cursor = (unsigned*)(ws + ou);
+    a.seg = (unsigned*)(ws + og); a.sorted = (unsigned*)(ws + os);
+    if (hipMemsetAsync(ws + oc, 0, og - oc, s) != hipSuccess)
+        return fail(YDET_ERR_LAUNCH, "nms_perclass: hipMemsetAsync failed");
+    const long long total = (long long)N * n;
+    const unsigned g1 = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(fa_score_kernel, dim3(g1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(fa_scatter_kernel, dim3(g1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(fa_rank_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nc, (unsigned)N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(fa_nms_kernel, dim3((unsigned)nc, (unsigned)N), dim3(256), 0, s, a);
+    YDET_CHECK_LAUNCH("nms_perclass kernels");
+    return YDET_OK;
+}
+
+extern "C" int ydet_box_iou(const float* a, int na, const float* b, int nb, float* iou, void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(na >= 0 && nb >= 0, "box_iou: negative size");
+    if (na == 0 || nb == 0) return YDET_OK;
+    YDET_CHECK_ARG(a && b && iou, "box_iou: null pointer");
+    YDET_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "box_iou: boxes must be 16-byte aligned");
+    const long long total = (long long)na * nb;
+    hipLaunchKernelGGL(box_iou_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (const float4*)a, na, (const float4*)b, nb, iou);
+    YDET_CHECK_LAUNCH("box_iou_kernel");
+    return YDET_OK;
+}

@@ -1,0 +1,66 @@
+// Error reporting and the launch-list executor of libydet.so.
+#include <string.h>
+
+#include "ydet_internal.h"
+
+int ydet_launch_slice(int op_kind, const ydet_slice_desc* d, int mode, hipStream_t stream);
+int ydet_launch_nchw_to_nhwc(const void* x, void* y, int N, int C, int H, int W, int y_ld, int y_coff, int c_pad,
+                             int x_dtype, int y_dtype, int focus, hipStream_t stream);
+int ydet_launch_nhwc_to_nchw(const void* x, void* y, int N, int C, int H, int W, int x_ld, int x_coff, int x_dtype,
+                             int y_dtype, hipStream_t stream);
+
+namespace ydet {
+
+static thread_local char g_err[512] = {0};
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+void clear_error() { g_err[0] = 0; }
+
+}  // namespace ydet
+
+extern "C" const char* ydet_last_error(void) { return ydet::g_err; }
+extern "C" int ydet_abi_version(void) { return 1; }
+
+// Runs a pre-planned forward pass: every op is validated and enqueued on `stream` in order; the
+// first failure stops the walk and is reported with the op index.
+extern "C" int ydet_run_ops(const ydet_op* ops, int n_ops, void* stream) {
+    ydet::clear_error();
+    if (n_ops < 0 || (n_ops > 0 && !ops)) return ydet::fail(YDET_ERR_ARG, "run_ops: bad op list");
+    hipStream_t s = ydet::as_stream(stream);
+    for (int i = 0; i < n_ops; ++i) {
+        const ydet_op& op = ops[i];
+        int rc;
+        switch (op.kind) {
+            case YDET_OP_CONV: rc = ydet_launch_conv(&op.conv, s); break;
+            case YDET_OP_MAXPOOL2:
+            case YDET_OP_MAXPOOL2S1:
+            case YDET_OP_SPP:
+            case YDET_OP_UPSAMPLE:
+            case YDET_OP_SPACE2DEPTH:
+            case YDET_OP_COPY: rc = ydet_launch_slice(op.kind, &op.slice, op.iarg, s); break;
+            case YDET_OP_NCHW2NHWC:
+                rc = ydet_launch_nchw_to_nhwc(op.slice.x, op.slice.y, op.slice.N, op.slice.C, op.slice.H, op.slice.W,
+                                              op.slice.y_ld, op.slice.y_coff, op.iarg2, op.iarg3, op.slice.dtype,
+                                              op.iarg, s);
+                break;
+            case YDET_OP_NHWC2NCHW:
+                rc = ydet_launch_nhwc_to_nchw(op.slice.x, op.slice.y, op.slice.N, op.slice.C, op.slice.H, op.slice.W,
+                                              op.slice.x_ld, op.slice.x_coff, op.slice.dtype, op.iarg3, s);
+                break;
+            default: rc = ydet::fail(YDET_ERR_ARG, "unknown op kind %d", op.kind); break;
+        }
+        if (rc != YDET_OK) {
+            char msg[400];
+            strncpy(msg, ydet::g_err, sizeof(msg) - 1);
+            msg[sizeof(msg) - 1] = 0;
+            return ydet::fail(rc, "run_ops: op %d of %d: %s", i, n_ops, msg);
+        }
+    }
+    return YDET_OK;
+}

@@ -1,0 +1,64 @@
+"""Data-parallel sharding of detection inference: one process per GPU, images partitioned across
+ranks, and ONE exchange step -- an all-gather of the fixed-shape per-image detections -- when a
+metric over the whole set is needed.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type="cuda"):
+    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1.
+    Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous [start, stop) of `n` items owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(t):
+    """Concatenate the rows (dim 0) of `t` from every rank, in rank order; row counts may differ.
+    One all-reduce(MAX) of the row count + one all_gather of the padded tensor."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    padded = t.new_zeros((m,) + tuple(t.shape[1:]))
+    padded[: t.shape[0]] = t
+    out = t.new_empty((ws * m,) + tuple(t.shape[1:]))
+    dist.all_gather_into_tensor(out, padded.contiguous())
+    return torch.cat([out[r * m: r * m + c] for r, c in enumerate(counts)], 0)
+
+
+def all_gather_detections(det, count, image_id):
+    """det [B, max_det, 6] fp32, count [B] int32, image_id [B] int64 (global image indices) of this
+    rank's shard -> the same three tensors for the whole set, sorted by image id."""
+    det_all = all_gather_rows(det)
+    cnt_all = all_gather_rows(count)
+    ids_all = all_gather_rows(image_id)
+    order = torch.argsort(ids_all)
+    return det_all[order], cnt_all[order], ids_all[order]

@@ -1,0 +1,461 @@
+"""Launch-list planner for the detection forward pass.
+
+A model is lowered ONCE per (batch, height, width, compute dtype) into a flat list of `ydet_op`
+records over NHWC device buffers; running the model is then a single C call (`ydet_run_ops`).
+
+Layout decisions
+  * activations are NHWC slices `(storage, channel offset, channels)`; a `torch.cat(dim=1)` in the
+    reference becomes "producers write into channel slices of one storage" (`Graph.cat` redirects
+    the producers' storages, no copy kernel unless a tensor is concatenated twice);
+  * BatchNorm is folded into packed weights `[cout_pad][kp]` (k = (kh*KW+kw)*Cin + c) and an fp32
+    bias; post-concat BatchNorms (CSP blocks) are folded per half into the producing convs;
+  * compute dtype "bf16": bf16 activations/weights, fp32 accumulate, fp32 detection-head outputs;
+    compute dtype "fp32": everything fp32 (exact-fp32 MFMA).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _ffi
+
+_TORCH_DT = {_ffi.F32: torch.float32, _ffi.BF16: torch.bfloat16}
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class Storage:
+    """One NHWC device buffer [N, H, W, ld]; may be redirected into a channel range of another."""
+
+    def __init__(self, N, H, W, ld, dtype, external=False):
+        self.N, self.H, self.W, self.ld, self.dtype = N, H, W, ld, dtype
+        self.external = external  # pointer supplied per call
+        self.parent = None
+        self.parent_off = 0
+        self.tensor = None
+
+    def root(self):
+        st, off = self, 0
+        while st.parent is not None:
+            off += st.parent_off
+            st = st.parent
+        return st, off
+
+
+class T:
+    """A channel slice of a storage: `C` meaningful channels starting at `coff`."""
+
+    def __init__(self, st, coff, C):
+        self.st, self.coff, self.C = st, coff, C
+
+    N = property(lambda s: s.st.N)
+    H = property(lambda s: s.st.H)
+    W = property(lambda s: s.st.W)
+    dtype = property(lambda s: s.st.dtype)
+
+    def resolve(self):
+        root, off = self.st.root()
+        return root, off + self.coff
+
+    def whole(self):
+        return self.coff == 0 and self.C == self.st.ld
+
+
+class PackedConv:
+    """Device-resident packed weights + bias of one (conv [+ BatchNorm]) for one input layout."""
+
+    def __init__(self, w, b, Cin, Cout, KH, KW, kp, cout_pad):
+        self.w, self.b, self.Cin, self.Cout, self.KH, self.KW, self.kp, self.cout_pad = w, b, Cin, Cout, KH, KW, kp, cout_pad
+
+
+def pack_conv(conv, bn=None, bn_slice=None, cin_phys=None, dtype=_ffi.BF16, device=None):
+    """Fold `bn` (optionally the channel range `bn_slice` of a wider BatchNorm) into `conv` and pack.
+
+    y = gamma * (conv(x) + bias - mean) / sqrt(var + eps) + beta, as nn.BatchNorm2d in eval mode.
+    """
+    if conv.groups != 1 or tuple(conv.dilation) != (1, 1):
+        raise NotImplementedError("grouped / dilated convolutions are outside the accelerated path")
+    if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
+        raise NotImplementedError("only square kernels / strides / paddings are used by the reference models")
+    device = device or conv.weight.device
+    w = conv.weight.detach().to(device=device, dtype=torch.float32)
+    Cout, Cin, KH, KW = w.shape
+    b = conv.bias.detach().to(device=device, dtype=torch.float32) if conv.bias is not None else torch.zeros(Cout, device=device)
+    if bn is not None:
+        sl = slice(*bn_slice) if bn_slice is not None else slice(None)
+        g = bn.weight.detach().to(device=device, dtype=torch.float32)[sl]
+        beta = bn.bias.detach().to(device=device, dtype=torch.float32)[sl]
+        mean = bn.running_mean.detach().to(device=device, dtype=torch.float32)[sl]
+        var = bn.running_var.detach().to(device=device, dtype=torch.float32)[sl]
+        scale = g / torch.sqrt(var + bn.eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = (b - mean) * scale + beta
+    cin_phys = cin_phys or Cin
+    epc = 8 if dtype == _ffi.BF16 else 4
+    if cin_phys % epc:
+        raise ValueError(f"input channel count {cin_phys} must be a multiple of {epc}")
+    w = w.permute(0, 2, 3, 1)
+    if cin_phys > Cin:
+        w = torch.nn.functional.pad(w, (0, cin_phys - Cin))
+    K = KH * KW * cin_phys
+    kp = _round_up(K, 4 * epc)
+    cout_pad = _round_up(Cout, 128)
+    wp = torch.zeros(cout_pad, kp, device=device, dtype=torch.float32)
+    wp[:Cout, :K] = w.reshape(Cout, K)
+    bp = torch.zeros(cout_pad, device=device, dtype=torch.float32)
+    bp[:Cout] = b
+    return PackedConv(wp.to(_TORCH_DT[dtype]).contiguous(), bp, cin_phys, Cout, KH, KW, kp, cout_pad)
+
+
+class Graph:
+    def __init__(self, device, compute="bf16"):
+        if compute not in ("bf16", "fp32"):
+            raise ValueError("compute dtype must be 'bf16' or 'fp32'")
+        self.device = torch.device(device)
+        self.dt = _ffi.BF16 if compute == "bf16" else _ffi.F32
+        self.vec = 8 if self.dt == _ffi.BF16 else 4
+        self.ops = []        # (kind, dict) records, resolved in finalize()
+        self.storages = []
+        self.keep = []       # tensors the plan must keep alive (packed weights)
+        self.ext_in = []     # op indices of the NCHW sources, in argument order
+        self.outputs = {}    # name -> T of external outputs
+
+    # ---- storage helpers ---------------------------------------------------------------------
+    def new(self, N, H, W, Cch, dtype=None, external=False, ld=None):
+        dtype = self.dt if dtype is None else dtype
+        st = Storage(N, H, W, ld or _round_up(Cch, 4 if dtype == _ffi.F32 else 8), dtype, external)
+        self.storages.append(st)
+        return T(st, 0, Cch)
+
+    def input_nchw(self, N, Cch, H, W, focus=False, src_dtype=_ffi.F32):
+        """API edge: NCHW source -> NHWC (through the Focus slicing if asked), channels zero-padded."""
+        c_out = 4 * Cch if focus else Cch
+        Ho, Wo = (H // 2, W // 2) if focus else (H, W)
+        t = self.new(N, Ho, Wo, _round_up(c_out, self.vec))
+        self.ops.append(("nchw2nhwc", dict(y=t, N=N, C=Cch, H=H, W=W, focus=int(focus), c_pad=t.C, src_dtype=src_dtype)))
+        self.ext_in.append(len(self.ops) - 1)
+        return t
+
+    # ---- operators -----------------------------------------------------------------------------
+    def conv(self, x, conv, bn=None, bn_slice=None, act=_ffi.ACT_NONE, slope=0.0, res=None,
+             res_mode=_ffi.RES_NONE, out=None, out_dtype=None, external=False):
+        pc = pack_conv(conv, bn, bn_slice, cin_phys=x.C, dtype=self.dt, device=self.device)
+        self.keep.append(pc)
+        s, p = conv.stride[0], conv.padding[0]
+        Ho = (x.H + 2 * p - pc.KH) // s + 1
+        Wo = (x.W + 2 * p - pc.KW) // s + 1
+        if out is None:
+            out = self.new(x.N, Ho, Wo, pc.Cout, dtype=out_dtype, external=external)
+        assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, pc.Cout), "conv output shape mismatch"
+        if res is not None:
+            assert (res.N, res.H, res.W, res.C) == (out.N, out.H, out.W, out.C), "residual shape mismatch"
+        self.ops.append(("conv", dict(x=x, y=out, res=res, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
+                                      res_mode=res_mode if res is not None else _ffi.RES_NONE)))
+        return out
+
+    def _slice_op(self, kind, x, out, iarg=0):
+        self.ops.append((kind, dict(x=x, y=out, iarg=iarg)))
+        return out
+
+    def maxpool2(self, x):
+        return self._slice_op("maxpool2", x, self.new(x.N, x.H // 2, x.W // 2, x.C))
+
+    def maxpool2s1(self, x):
+        return self._slice_op("maxpool2s1", x, self.new(x.N, x.H, x.W, x.C))
+
+    def spp(self, x):
+        """x, pool5(x), pool9(x), pool13(x) concatenated on channels; x is redirected into slice 0."""
+        out = self.new(x.N, x.H, x.W, 4 * x.C)
+        x = self._place(x, out, 0)
+        self._slice_op("spp", x, T(out.st, x.C, 3 * x.C))
+        return out
+
+    def upsample2x(self, x, mode):
+        return self._slice_op("upsample", x, self.new(x.N, 2 * x.H, 2 * x.W, x.C), iarg=mode)
+
+    def space_to_depth(self, x, mode):
+        return self._slice_op("space2depth", x, self.new(x.N, x.H // 2, x.W // 2, 4 * x.C), iarg=mode)
+
+    def _place(self, t, dst, coff):
+        """Make `t` live at channels [coff, coff+C) of dst's storage: redirect if possible, else copy."""
+        st = t.st
+        if st.parent is None and not st.external and t.whole() and st.ld == t.C and st is not dst.st:
+            st.parent, st.parent_off = dst.st, dst.coff + coff
+            return t
+        piece = T(dst.st, dst.coff + coff, t.C)
+        self._slice_op("copy", t, piece)
+        return piece
+
+    def cat(self, ts):
+        N, H, W = ts[0].N, ts[0].H, ts[0].W
+        for t in ts:
+            assert (t.N, t.H, t.W) == (N, H, W), "cat: spatial mismatch"
+            if t.C % self.vec:
+                raise NotImplementedError("cat of channel counts that are not vector multiples")
+        out = self.new(N, H, W, sum(t.C for t in ts))
+        off = 0
+        for t in ts:
+            self._place(t, out, off)
+            off += t.C
+        return out
+
+    def to_nchw(self, x, name, dst_dtype=_ffi.F32):
+        """API edge: an NHWC slice returned to the caller as a fresh NCHW tensor."""
+        self.ops.append(("nhwc2nchw", dict(x=x, name=name, dst_dtype=dst_dtype)))
+
+    def output(self, name, t):
+        self.outputs[name] = t
+
+    # ---- finalize ------------------------------------------------------------------------------
+    def finalize(self):
+        return Plan(self)
+
+
+class Plan:
+    """Resolved launch list + the buffers it runs on."""
+
+    def __init__(self, g):
+        self.device = g.device
+        self.g = g
+        for st in g.storages:
+            root, _ = st.root()
+            if root is st and not st.external:
+                st.tensor = torch.empty(st.N, st.H, st.W, st.ld, device=g.device, dtype=_TORCH_DT[st.dtype])
+        n = len(g.ops)
+        self.ops = (_ffi.Op * n)()
+        self.patch_in = list(g.ext_in)  # op indices whose slice.x is a caller-supplied NCHW input
+        self.patch_out = []       # (op index, field, storage) of external NHWC outputs
+        self.nchw_out = []        # (op index, name, shape, dtype)
+        self._ext_storages = [st for st in g.storages if st.external]
+        for i, (kind, a) in enumerate(g.ops):
+            op = self.ops[i]
+            if kind == "conv":
+                self._fill_conv(i, op, a)
+            elif kind == "nchw2nhwc":
+                op.kind = _ffi.OP_NCHW2NHWC
+                root, off = a["y"].resolve()
+                s = op.slice
+                s.y = root.tensor.data_ptr()
+                s.N, s.C, s.H, s.W = a["N"], a["C"], a["H"], a["W"]
+                s.y_ld, s.y_coff, s.dtype = root.ld, off, root.dtype
+                op.iarg, op.iarg2, op.iarg3 = a["focus"], a["c_pad"], a["src_dtype"]
+            elif kind == "nhwc2nchw":
+                op.kind = _ffi.OP_NHWC2NCHW
+                x = a["x"]
+                root, off = x.resolve()
+                s = op.slice
+                s.x = self._ptr(root, i, "x")
+                s.N, s.C, s.H, s.W = x.N, x.C, x.H, x.W
+                s.x_ld, s.x_coff, s.dtype = root.ld, off, root.dtype
+                op.iarg3 = a["dst_dtype"]
+                self.nchw_out.append((i, a["name"], (x.N, x.C, x.H, x.W), _TORCH_DT[a["dst_dtype"]]))
+            else:
+                op.kind = {"maxpool2": _ffi.OP_MAXPOOL2, "maxpool2s1": _ffi.OP_MAXPOOL2S1, "spp": _ffi.OP_SPP,
+                           "upsample": _ffi.OP_UPSAMPLE, "space2depth": _ffi.OP_SPACE2DEPTH,
+                           "copy": _ffi.OP_COPY}[kind]
+                op.iarg = a["iarg"]
+                x, y = a["x"], a["y"]
+                rx, ox = x.resolve()
+                ry, oy = y.resolve()
+                assert rx.dtype == ry.dtype
+                s = op.slice
+                s.x, s.y = self._ptr(rx, i, "x"), self._ptr(ry, i, "y")
+                s.N, s.H, s.W, s.C = x.N, x.H, x.W, x.C
+                s.x_ld, s.x_coff, s.y_ld, s.y_coff, s.dtype = rx.ld, ox, ry.ld, oy, rx.dtype
+
+    def _ptr(self, root, i, field):
+        if root.external:
+            self.patch_out.append((i, field, root))
+            return 0
+        return root.tensor.data_ptr()
+
+    def _fill_conv(self, i, op, a):
+        op.kind = _ffi.OP_CONV
+        d = op.conv
+        x, y, res, pc = a["x"], a["y"], a["res"], a["pc"]
+        rx, ox = x.resolve()
+        ry, oy = y.resolve()
+        d.x = self._ptr(rx, i, "cx")
+        d.y = self._ptr(ry, i, "cy")
+        d.w, d.bias = pc.w.data_ptr(), pc.b.data_ptr()
+        d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
+        d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, pc.KH, pc.KW, a["stride"], a["pad"]
+        d.Ho, d.Wo = y.H, y.W
+        d.x_ld, d.x_coff, d.y_ld, d.y_coff = rx.ld, ox, ry.ld, oy
+        if res is not None:
+            rr, orr = res.resolve()
+            assert rr.dtype == rx.dtype
+            d.res, d.res_ld, d.res_coff = self._ptr(rr, i, "cres"), rr.ld, orr
+        d.kp, d.cout_pad = pc.kp, pc.cout_pad
+        d.act, d.slope, d.res_mode = a["act"], a["slope"], a["res_mode"]
+        d.in_dtype, d.out_dtype = rx.dtype, ry.dtype
+
+    def run(self, *xs):
+        """xs: the NCHW CUDA inputs (fp32 or bf16; other dtypes are converted to fp32), in the order
+        they were declared.  Returns {name: tensor} of the plan's outputs."""
+        lib = _ffi.lib()
+        assert len(xs) == len(self.patch_in), f"plan takes {len(self.patch_in)} inputs"
+        outs = {}
+        held = []
+        for st in self._ext_storages:
+            st.tensor = torch.empty(st.N, st.H, st.W, st.ld, device=self.device, dtype=_TORCH_DT[st.dtype])
+        for i, x in zip(self.patch_in, xs):
+            if x.dtype not in (torch.float32, torch.bfloat16):
+                x = x.float()
+            x = x.contiguous()
+            held.append(x)
+            op = self.ops[i]
+            assert tuple(x.shape) == (op.slice.N, op.slice.C, op.slice.H, op.slice.W), \
+                f"plan built for {(op.slice.N, op.slice.C, op.slice.H, op.slice.W)}, got {tuple(x.shape)}"
+            op.slice.x = x.data_ptr()
+            op.iarg3 = _ffi.BF16 if x.dtype == torch.bfloat16 else _ffi.F32
+        for i, field, root in self.patch_out:
+            ptr = root.tensor.data_ptr()
+            op = self.ops[i]
+            if field == "x":
+                op.slice.x = ptr
+            elif field == "y":
+                op.slice.y = ptr
+            elif field == "cx":
+                op.conv.x = ptr
+            elif field == "cy":
+                op.conv.y = ptr
+            else:
+                op.conv.res = ptr
+        for i, name, shape, dt in self.nchw_out:
+            t = torch.empty(shape, device=self.device, dtype=dt)
+            self.ops[i].slice.y = t.data_ptr()
+            outs[name] = t
+        with torch.cuda.device(self.device):
+            _ffi.check(lib.ydet_run_ops(self.ops, len(self.ops), _ffi.current_stream()), "ydet_run_ops")
+        for name, t in self.g.outputs.items():
+            root, off = t.resolve()
+            outs[name] = root.tensor[..., off:off + t.C]
+        return outs
+
+
+class PlanCache:
+    """Per-model cache of plans keyed by (input shape, compute dtype); dropped when weights move."""
+
+    def __init__(self):
+        self.plans = {}
+
+    def clear(self):
+        self.plans.clear()
+
+    def get(self, key, build):
+        p = self.plans.get(key)
+        if p is None:
+            p = self.plans[key] = build()
+        return p
+
+
+_compute_override = None
+
+
+def set_compute_dtype(name):
+    """Force the compute dtype of the accelerated path: 'bf16', 'fp32' or None (follow the weights)."""
+    global _compute_override
+    if name not in (None, "bf16", "fp32"):
+        raise ValueError(name)
+    _compute_override = name
+
+
+def compute_dtype_for(module):
+    """fp32 parameters -> exact-fp32 MFMA path; half/bf16 parameters -> bf16 path."""
+    if _compute_override is not None:
+        return _compute_override
+    p = next(module.parameters())
+    return "fp32" if p.dtype == torch.float32 else "bf16"
+
+
+class AcceleratedModule(torch.nn.Module):
+    """Mixin for the top-level detectors: owns the plan cache and invalidates it when weights change."""
+
+    def _plans(self):
+        pc = self.__dict__.get("_ydet_plan_cache")
+        if pc is None:
+            pc = self.__dict__["_ydet_plan_cache"] = PlanCache()
+        return pc
+
+    def invalidate_plans(self):
+        self._plans().clear()
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_plans()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_plans()
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        self.invalidate_plans()
+        return super().train(mode)
+
+
+# ---- lowering of plain torch.nn containers / layers ---------------------------------------------
+def lower_any(g, m, x):
+    """Lower a module onto graph `g`: blocks with a `lower` method, nn.Sequential chains,
+    MaxPool2d(2,2), ZeroPad2d((0,1,0,1)) + MaxPool2d(2,1), nn.Upsample(x2) and bare nn.Conv2d."""
+    nn = torch.nn
+    if hasattr(m, "lower"):
+        return m.lower(g, x)
+    if isinstance(m, nn.Sequential):
+        mods = list(m)
+        i = 0
+        while i < len(mods):
+            cur = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(cur, nn.ZeroPad2d) and tuple(cur.padding) == (0, 1, 0, 1) and _is_pool(nxt, 2, 1):
+                x = g.maxpool2s1(x)
+                i += 2
+                continue
+            x = lower_any(g, cur, x)
+            i += 1
+        return x
+    if _is_pool(m, 2, 2):
+        return g.maxpool2(x)
+    if isinstance(m, nn.Upsample):
+        from .yolov5_official.modules import lower_upsample
+        return lower_upsample(g, m, x)
+    if isinstance(m, nn.Conv2d):
+        return g.conv(x, m)
+    if isinstance(m, nn.Identity):
+        return x
+    raise NotImplementedError(f"{type(m).__name__} has no HIP lowering")
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def _is_pool(m, k, s):
+    return (isinstance(m, torch.nn.MaxPool2d) and _pair(m.kernel_size) == (k, k) and _pair(m.stride) == (s, s)
+            and _pair(m.padding) == (0, 0) and _pair(m.dilation) == (1, 1) and not m.ceil_mode)
+
+
+class TorchOps:
+    """Eager face of a network wiring written against (run, cat)."""
+    @staticmethod
+    def run(m, x):
+        return m(x)
+
+    @staticmethod
+    def cat(xs):
+        return torch.cat(xs, 1)
+
+
+class LowerOps:
+    """Graph-emitting face of the same wiring."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def run(self, m, x):
+        return lower_any(self.g, m, x)
+
+    def cat(self, xs):
+        return self.g.cat(list(xs))

@@ -1,0 +1,68 @@
+"""Checkpoint-compatibility copies of the YOLOv5 blocks (reference models/common.py): identical to
+yolo_amd.yolov5_official.modules except that `Conv` activates with nn.LeakyReLU() (slope 0.01), plus
+the `NMS` wrapper module.  The class paths `models.common.*` are what upstream pickles refer to."""
+import torch.nn as nn
+
+from ..yolov5_official import modules as _m
+from ..yolov5_official.modules import autopad, Concat, Contract, Expand  # noqa: F401
+from ..yolov5_official.utils import non_max_suppression
+
+
+class Conv(_m.Conv):
+    default_act = staticmethod(lambda: nn.LeakyReLU())
+
+
+def DWConv(c1, c2, k=1, s=1, act=True):
+    import math
+    return Conv(c1, c2, k, s, g=math.gcd(c1, c2), act=act)
+
+
+def _rebuild(block, attrs):
+    """Swap the SiLU `Conv`s a parent-class constructor created for LeakyReLU(0.01) ones of equal shape."""
+    for name in attrs:
+        old = getattr(block, name)
+        c = old.conv
+        setattr(block, name, Conv(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0],
+                                  c.groups, act=old.act is not None))
+
+
+class Bottleneck(_m.Bottleneck):
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__(c1, c2, shortcut, g, e)
+        _rebuild(self, ("cv1", "cv2"))
+
+
+class BottleneckCSP(_m.BottleneckCSP):
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__(c1, c2, n, shortcut, g, e)
+        c_ = int(c2 * e)
+        _rebuild(self, ("cv1", "cv4"))
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+
+class C3(_m.C3):
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__(c1, c2, n, shortcut, g, e)
+        c_ = int(c2 * e)
+        _rebuild(self, ("cv1", "cv2", "cv3"))
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+
+class SPP(_m.SPP):
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__(c1, c2, k)
+        _rebuild(self, ("cv1", "cv2"))
+
+
+class Focus(_m.Focus):
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__(c1, c2, k, s, p, g, act)
+        _rebuild(self, ("conv",))
+
+
+class NMS(nn.Module):
+    """Module form of non_max_suppression (reference models/common.py:203-214)."""
+    conf, iou, classes, max_det = 0.25, 0.45, None, 1000
+
+    def forward(self, x):
+        return non_max_suppression(x[0], self.conf, iou_thres=self.iou, classes=self.classes, max_det=self.max_det)

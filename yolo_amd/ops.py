@@ -1,0 +1,146 @@
+"""Tensor-level wrappers of the decode / NMS / IoU entry points of libydet.so.
+
+Inputs and outputs are CUDA tensors; everything is enqueued on torch's current stream and nothing
+here synchronises with the host.
+"""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return _ffi.F32
+    if t.dtype == torch.bfloat16:
+        return _ffi.BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("yolo_amd GPU operator called with a CPU tensor (there is no CPU path here)")
+
+
+def decode_v5(heads, strides, anchors_px, na, no, grid_transposed=False):
+    """heads: NHWC maps [N, ny, nx, >=na*no] (fp32 or bf16, last dim contiguous), one per level.
+    strides: per-level float; anchors_px: per-level list of 2*na pixel sizes.
+    Returns z [N, sum(na*ny*nx), no] fp32 (yolov5_official/model.py:56-81)."""
+    _need_cuda(*heads)
+    lib = _ffi.lib()
+    nl = len(heads)
+    N = heads[0].shape[0]
+    levels = (_ffi.V5Level * nl)()
+    rows = 0
+    for l, h in enumerate(heads):
+        assert h.dim() == 4 and h.stride(3) == 1 and h.shape[0] == N
+        assert h.stride(2) == h.stride(1) // h.shape[2] and h.stride(0) == h.stride(1) * h.shape[1], "head not NHWC-dense"
+        L = levels[l]
+        L.head, L.ny, L.nx, L.ld = h.data_ptr(), h.shape[1], h.shape[2], h.stride(2)
+        L.stride = float(strides[l])
+        for i, v in enumerate(anchors_px[l]):
+            L.anchor_wh[i] = float(v)
+        rows += na * h.shape[1] * h.shape[2]
+    out = torch.empty(N, rows, no, device=heads[0].device, dtype=torch.float32)
+    with torch.cuda.device(out.device):
+        _ffi.check(lib.ydet_decode_v5(levels, nl, N, na, no, int(grid_transposed), _dt(heads[0]), out.data_ptr(),
+                                      _ffi.current_stream()), "ydet_decode_v5")
+    return out
+
+
+def decode_v2v3(heads, anchors, A, nc, mode, input_size, mult=32.0, grid_transposed=True):
+    """heads: NHWC maps [N, H, W, >=A*(5+nc)] fine -> coarse; anchors: per-level list of 2*A values.
+    mode 0 = utils/utils.py xywh_to_xxyy ("v2"), 1 = xywh_to_xxyyv3.
+    Returns (boxes [N, n, 4] normalised+clamped xyxy, scores [N, n, nc]) fp32."""
+    _need_cuda(*heads)
+    lib = _ffi.lib()
+    nl = len(heads)
+    N = heads[0].shape[0]
+    levels = (_ffi.FALevel * nl)()
+    n = 0
+    for l, h in enumerate(heads):
+        assert h.dim() == 4 and h.stride(3) == 1 and h.shape[0] == N
+        assert h.stride(2) == h.stride(1) // h.shape[2] and h.stride(0) == h.stride(1) * h.shape[1], "head not NHWC-dense"
+        L = levels[l]
+        L.head, L.H, L.W, L.ld = h.data_ptr(), h.shape[1], h.shape[2], h.stride(2)
+        for i, v in enumerate(anchors[l]):
+            L.anchor_wh[i] = float(v)
+        n += A * h.shape[1] * h.shape[2]
+    dev = heads[0].device
+    boxes = torch.empty(N, n, 4, device=dev, dtype=torch.float32)
+    scores = torch.empty(N, n, nc, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _ffi.check(lib.ydet_decode_v2v3(levels, nl, N, A, nc, int(mode), float(mult), float(input_size),
+                                        int(grid_transposed), _dt(heads[0]), boxes.data_ptr(), scores.data_ptr(),
+                                        _ffi.current_stream()), "ydet_decode_v2v3")
+    return boxes, scores
+
+
+def nms_v5(pred, conf_thres=0.25, iou_thres=0.45, multi_label=False, agnostic=False, max_det=300, max_nms=None,
+           max_wh=4096.0, classes=None):
+    """pred [N, nboxes, 5+nc] fp32 CUDA.  Returns (det [N, max_det, 6], count [N] int32) on the device;
+    det rows are (x1, y1, x2, y2, score, cls) in descending score order."""
+    _need_cuda(pred)
+    lib = _ffi.lib()
+    if pred.dtype != torch.float32:
+        pred = pred.float()
+    pred = pred.contiguous()
+    N, nboxes, no = pred.shape
+    max_nms = max_det if max_nms is None else max_nms
+    dev = pred.device
+    det = torch.empty(N, max_det, 6, device=dev, dtype=torch.float32)
+    count = torch.empty(N, device=dev, dtype=torch.int32)
+    if N == 0 or nboxes == 0:
+        return det.zero_(), count.zero_()
+    ws_bytes = lib.ydet_nms_v5_workspace_bytes(N, nboxes, no)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    mask_ptr = None
+    if classes is not None:
+        m = torch.zeros(no - 5, dtype=torch.uint8)
+        m[torch.as_tensor(list(classes), dtype=torch.long)] = 1
+        mask = m.to(dev)
+        mask_ptr = mask.data_ptr()
+    with torch.cuda.device(dev):
+        _ffi.check(lib.ydet_nms_v5(pred.data_ptr(), N, nboxes, no, float(conf_thres), float(iou_thres),
+                                   int(bool(multi_label)), int(bool(agnostic)), int(max_nms), int(max_det),
+                                   float(max_wh), mask_ptr, det.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                   ws_bytes, _ffi.current_stream()), "ydet_nms_v5")
+    return det, count
+
+
+def nms_perclass(boxes, scores, conf_thresh, nms_thresh):
+    """boxes [N, n, 4], scores [N, n, nc] fp32 CUDA.
+    Returns (keep [N, n] uint8, cls [N, n] int32, best [N, n] fp32): utils/utils.py:101-133."""
+    _need_cuda(boxes, scores)
+    lib = _ffi.lib()
+    boxes = boxes.float().contiguous()
+    scores = scores.float().contiguous()
+    N, n, nc = scores.shape
+    dev = boxes.device
+    keep = torch.empty(N, n, device=dev, dtype=torch.uint8)
+    cls = torch.empty(N, n, device=dev, dtype=torch.int32)
+    best = torch.empty(N, n, device=dev, dtype=torch.float32)
+    if N == 0 or n == 0:
+        return keep, cls, best
+    ws_bytes = lib.ydet_nms_perclass_workspace_bytes(N, n, nc)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _ffi.check(lib.ydet_nms_perclass(boxes.data_ptr(), scores.data_ptr(), N, n, nc, float(conf_thresh),
+                                         float(nms_thresh), keep.data_ptr(), cls.data_ptr(), best.data_ptr(),
+                                         ws.data_ptr(), ws_bytes, _ffi.current_stream()), "ydet_nms_perclass")
+    return keep, cls, best
+
+
+def box_iou(box1, box2):
+    """IoU matrix [n1, n2] of xyxy boxes (yolov5_official/utils.py:601-611)."""
+    _need_cuda(box1, box2)
+    lib = _ffi.lib()
+    a = box1.float().contiguous()
+    b = box2.float().contiguous()
+    out = torch.empty(a.shape[0], b.shape[0], device=a.device, dtype=torch.float32)
+    with torch.cuda.device(a.device):
+        _ffi.check(lib.ydet_box_iou(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(),
+                                    _ffi.current_stream()), "ydet_box_iou")
+    return out
