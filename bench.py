@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of YOLOv5s 640x640 forward + Detect decode + NMS, batch 64 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--compute bf16|fp32] [--batch 64] [--no-cpu]
+
+One step = one batch of synthetic images (already resident in HBM) through
+    Model.forward (HIP launch list + fused decode)  ->  non_max_suppression (validation regime of the
+    reference's val.run: conf 0.001, iou 0.6, multi_label)  ->  async D2H of the padded detections.
+N > 1: one process per GPU (torch.distributed / RCCL); images are independent, so each rank owns its own
+batch (weak scaling) and the data path has no collective.  Timing: barrier + synchronize on both sides of
+exactly K steps, max over ranks; rank 0 prints ONE JSON line.
+
+roofline: the conv kernels are MFMA-bound work; hipEvents recorded between the ops of the launch list during
+the timed steps give each kernel's device time, and achieved = algorithmic conv FLOPs / that time
+(peak: 2.5 PFLOP/s dense bf16, 157.3 TFLOP/s fp32).  cpu_baseline: the oracle's CPU restatement of the
+same path (stock torch CPU ops + numpy decode / NMS) on a bounded sample, rank 0 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_IMAGE = 16.96   # YOLOv5s nc=80 at 640x640, conv MACs x 2 (measured on the reference's nn.Conv2d calls)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import yolo_amd
+    from yolo_amd import _ffi, distributed as ydist, engine
+    from yolo_amd.synthetic import images, init_deterministic
+    from yolo_amd.yolov5_official.model import Model
+    from yolo_amd.yolov5_official.utils import non_max_suppression_padded
+
+    rank, world, local = ydist.init_from_env("cuda")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    lib = _ffi.lib()
+
+    engine.set_compute_dtype(args.compute)
+    model = Model()
+    init_deterministic(model, seed=0, head_convs=list(model.model[-1].m))
+    model = model.to(dev).eval()
+    x = images(args.batch, args.size, seed=100 + rank).to(dev)
+    pinned_det = torch.empty(args.batch, 300, 6, pin_memory=True)
+    pinned_cnt = torch.empty(args.batch, dtype=torch.int32, pin_memory=True)
+
+    plan_holder = {}
+
+    def step(timer=None, mark=0, ev=None):
+        compute = engine.compute_dtype_for(model)
+        key = (tuple(x.shape), compute, x.device.index)
+        plan = model._plans().get(key, lambda: _build(model, x, compute))
+        plan_holder["plan"] = plan
+        outs = plan.run(x, timer=timer, first_mark=mark)
+        det_head = model.model[-1]
+        if ev is not None:
+            ev[0].record()
+        z, _ = det_head.decode([outs[f"head{i}"] for i in range(det_head.nl)])
+        if ev is not None:
+            ev[1].record()
+        det, cnt = non_max_suppression_padded(z, 0.001, 0.6, multi_label=True)
+        if ev is not None:
+            ev[2].record()
+        pinned_det.copy_(det, non_blocking=True)
+        pinned_cnt.copy_(cnt, non_blocking=True)
+        return cnt
+
+    def _build(m, xx, compute):
+        g = engine.Graph(xx.device, compute)
+        m._lower(g, *xx.shape)
+        return g.finalize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        n_ops = len(plan_holder["plan"].ops)
+        timer = lib.ydet_timer_create(args.steps * (n_ops + 1))
+        if not timer:
+            raise RuntimeError("ydet_timer_create failed")
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(timer, k * (n_ops + 1), evs[k])
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel device times from the events recorded during the timed steps ----------------------
+    plan = plan_holder["plan"]
+    per_label = {}
+    buf = (ctypes.c_float * n_ops)()
+    for k in range(args.steps):
+        _ffi.check(lib.ydet_timer_elapsed(timer, k * (n_ops + 1), n_ops, buf), "ydet_timer_elapsed")
+        for i, info in enumerate(plan.op_info):
+            d = per_label.setdefault(info["label"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            d["ms"] += buf[i]; d["launches"] += 1; d["flops"] += info["flops"]; d["bytes"] += info["bytes"]
+    lib.ydet_timer_destroy(timer)
+    decode_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
+    nms_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+    conv = {k: v for k, v in per_label.items() if k.startswith("conv")}
+    conv_ms = sum(v["ms"] for v in conv.values())
+    conv_flops = sum(v["flops"] for v in conv.values())
+    dom_label, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
+    peak = PEAK_TFLOPS[args.compute]
+    dom_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    stack_tf = conv_flops / (conv_ms * 1e-3) / 1e12
+    kernels = {k: dict(avg_us=round(v["ms"] / v["launches"] * 1e3, 2), launches_per_step=v["launches"] // args.steps,
+                       tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                       gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+               for k, v in sorted(per_label.items(), key=lambda kv: -kv[1]["ms"])}
+
+    n_boxes = 3 * (args.size // 8) ** 2 + 3 * (args.size // 16) ** 2 + 3 * (args.size // 32) ** 2
+    decode_bytes = 2.0 * args.batch * n_boxes * 85 * 4
+    nms_bytes = args.batch * n_boxes * 85 * 4 + args.batch * 300 * 6 * 4
+
+    result = {
+        "metric": "images/sec (fwd+decode+NMS) YOLOv5s 640 bs64",
+        "value": round(world * args.batch * args.steps / elapsed, 2),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.compute,
+        "data": "synthetic",
+        "config": {"workload": f"YOLOv5s (yolov5_official/model.py) {args.size}x{args.size}, batch {args.batch} per GPU, "
+                               "forward + Detect decode + NMS (conf 0.001, iou 0.6, multi_label, max_det 300)",
+                   "images_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                   "weights": "seeded synthetic (yolo_amd.synthetic.init_deterministic)"},
+        "roofline": {"bound": "mfma", "kernel": dom_label, "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(dom_tf / peak, 4), "traffic": None,
+                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
+                     "flops_per_launch": dom["flops"] / dom["launches"]},
+        "conv_stack": {"tflops": round(stack_tf, 2), "mfma_util_frac": round(stack_tf / peak, 4),
+                       "ms_per_step": round(conv_ms / args.steps, 3),
+                       "gflop_per_image": round(conv_flops / args.steps / args.batch / 1e9, 3)},
+        "decode": {"ms_per_step": round(decode_ms, 3), "gbs": round(decode_bytes / (decode_ms * 1e-3) / 1e9, 1),
+                   "frac_of_hbm_peak": round(decode_bytes / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "nms": {"ms_per_step": round(nms_ms, 3), "gbs": round(nms_bytes / (nms_ms * 1e-3) / 1e9, 1),
+                "frac_of_hbm_peak": round(nms_bytes / (nms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "kernels": kernels,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(model, args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(model, args):
+    """The oracle (CPU restatement: oracle/nets.py + oracle/postproc.py) on the host cores, bounded sample."""
+    import yaml
+    from oracle import nets as ON
+    from oracle import postproc as OP
+    from yolo_amd.synthetic import images
+    from yolo_amd.yolov5_official.model import DEFAULT_CFG
+    with open(DEFAULT_CFG) as fh:
+        cfg = yaml.safe_load(fh)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    det = model.model[-1]
+    strides = [float(s) for s in det.stride]
+    anchor_grid = det.anchor_grid.detach().float().cpu().view(det.nl, det.na, 2).numpy()
+    cores = torch.get_num_threads()
+    bs = 4
+    x = images(bs, args.size, seed=100)
+
+    def one():
+        with torch.no_grad():
+            heads = ON.yolov5_heads(sd, x, cfg)
+        z, _ = OP.detect_decode([h.numpy() for h in heads], strides, anchor_grid, det.na, det.no)
+        OP.non_max_suppression(z, 0.001, 0.6, multi_label=True)
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += bs
+        if time.perf_counter() - t0 > args.cpu_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} images of {args.size}x{args.size} in batches of {bs}, fp32, same weights, "
+                      f"forward+decode+NMS (conf 0.001, iou 0.6, multi_label), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

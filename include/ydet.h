@@ -133,8 +133,9 @@ typedef struct {
     float anchor_wh[2 * 8]; /* pixel anchors (w,h) per anchor, na <= 8 */
 } ydet_v5_level;
 
-/* Detect.forward in eval mode: yolov5_official/model.py:56-81 (grid_transposed = 0) and
- * models/yolo.py:42-71 (grid_transposed = 1).
+/* Detect.forward in eval mode: yolov5_official/model.py:56-81 (grid_transposed = 0: cell (row, col)
+ * holds the offset (col, row)) and models/yolo.py:42-71 (grid_transposed = 1: its np.meshgrid table makes
+ * flat cell f = row*nx + col hold (f / ny, f % ny), which is (row, col) on square maps).
  *   s = sigmoid(raw); xy = (2 s - 0.5 + grid) * stride; wh = (2 s)^2 * anchor; rest = s
  * out is [N, sum_l na*ny*nx, no] fp32, row = offset(level) + (a*ny + row)*nx + col. */
 int ydet_decode_v5(const ydet_v5_level* levels /* host */, int nl, int N, int na, int no,
@@ -151,8 +152,9 @@ typedef struct {
  *   conf = sigmoid(ch a); cls = softmax over ch A + a*nc + c; score = cls * conf
  *   mode 0 ("v2", xywh_to_xxyy):   c = (sigmoid(t_xy) + g) * mult;  wh = exp(t_wh) * anchor * mult
  *   mode 1 ("v3", xywh_to_xxyyv3): c = (sigmoid(t_xy) + g) * mult;  wh = exp(t_wh) * anchor
- *   box = clamp((c -/+ wh/2) / input_size, 0, 1); g = (row, col) -- the reference's grid is
- *   transposed (utils/utils.py:167-169) -- unless grid_transposed = 0.
+ *   box = clamp((c -/+ wh/2) / input_size, 0, 1); g = (k / H, k % H) for flat cell k = row*W + col -- the
+ *   reference's grid (utils/utils.py:167-169), i.e. (row, col) on its square maps -- or (col, row) when
+ *   grid_transposed = 0.
  * boxes [N, n, 4], scores [N, n, nc], n = sum_l H*W*A, box index = offset(level) + (row*W+col)*A + a. */
 int ydet_decode_v2v3(const ydet_fa_level* levels /* host */, int nl, int N, int A, int nc, int mode,
                      float mult, float input_size, int grid_transposed, int head_dtype,
@@ -219,6 +221,16 @@ typedef struct {
 } ydet_op;
 
 int ydet_run_ops(const ydet_op* ops /* host */, int n_ops, void* stream);
+
+/* Measurement aid (no counterpart in the reference, which has no profiler): the same executor, but a
+ * hipEvent is recorded on `stream` before the first op and after every op, into marks
+ * first_mark .. first_mark + n_ops of `timer`.  Nothing synchronises; after the caller has synchronised
+ * the stream, ydet_timer_elapsed returns the milliseconds between consecutive marks. */
+typedef struct ydet_timer ydet_timer;
+ydet_timer* ydet_timer_create(int n_marks);
+void ydet_timer_destroy(ydet_timer* t);
+int ydet_run_ops_timed(const ydet_op* ops /* host */, int n_ops, void* stream, ydet_timer* t, int first_mark);
+int ydet_timer_elapsed(ydet_timer* t, int first_mark, int n_intervals, float* ms /* host */);
 
 #ifdef __cplusplus
 }

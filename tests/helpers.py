@@ -1,0 +1,66 @@
+"""Shared builders for the tests: seeded models (product mirrors) and their configuration."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from yolo_amd.models import model_config as mc  # noqa: E402
+from yolo_amd.synthetic import images, init_deterministic  # noqa: E402
+
+FA_SPECS = {
+    # tag: (module, class, config dict, head conv attribute names fine->coarse, decode is "v2", oracle net)
+    "v3tiny": ("yolo_amd.models.v3tiny", "YOLOv3", mc.yolov3_tiny_cfg, ["pred_1", "pred_2"], False, "v3tiny_heads"),
+    "v2d19": ("yolo_amd.models.v2d19", "YOLOv2", mc.yolov2_d19_cfg, ["pred"], True, "v2d19_heads"),
+    "v3spp": ("yolo_amd.models.v3spp", "YOLOv3", mc.yolov3_d53_cfg, ["pred_1", "pred_2", "pred_3"], True, "v3spp"),
+    "v3": ("yolo_amd.models.v3", "YOLOv3", mc.yolov3_d53_cfg, ["pred_1", "pred_2", "pred_3"], False, "v3"),
+    "v4": ("yolo_amd.models.v4", "YOLOv4", mc.yolov4_cfg, ["head_det_1", "head_det_2", "head_det_3"], True, "v4_heads"),
+}
+
+
+def build_fa(tag, size, seed=0):
+    import importlib
+    modname, cls, cfg, heads, v2, _ = FA_SPECS[tag]
+    net = getattr(importlib.import_module(modname), cls)(size, 20, False, anchor_size=cfg["anchor_size_voc"])
+    init_deterministic(net, seed=seed)
+    return net.eval()
+
+
+def oracle_fa_heads(tag, sd, x):
+    from oracle import nets
+    fn = FA_SPECS[tag][5]
+    if fn == "v3spp":
+        return nets.v3_heads(sd, x, spp=True)
+    if fn == "v3":
+        return nets.v3_heads(sd, x, spp=False)
+    return getattr(nets, fn)(sd, x)
+
+
+def fa_level_anchors(net):
+    return net._level_anchors()
+
+
+def build_v5s(nc=80, seed=0, compat=False):
+    if compat:
+        from yolo_amd.models.yolo import Model
+    else:
+        from yolo_amd.yolov5_official.model import Model
+    m = Model(nc=nc) if nc != 80 else Model()
+    init_deterministic(m, seed=seed, head_convs=list(m.model[-1].m))
+    return m.eval()
+
+
+def v5s_cfg():
+    import yaml
+    from yolo_amd.yolov5_official.model import DEFAULT_CFG
+    with open(DEFAULT_CFG) as fh:
+        return yaml.safe_load(fh)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))

@@ -1,0 +1,280 @@
+"""GPU parity of whole blocks and models (product mirrors running the HIP launch list) against the golden
+vectors captured from the reference and against the oracle networks.
+
+Tolerances (relative to the largest reference magnitude of the tensor compared):
+fp32 compute path 1e-3, bf16 compute path 2e-2 for single blocks; whole bf16 networks accumulate rounding
+over 60-125 layers and are held to 5e-2 on the raw head maps.  Kept-box results are compared exactly on
+the fp32 path when both sides are fed the same decoded boxes (that is what test_gpu_ops covers); here,
+end to end, the detections are compared as sets with a box tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import FA_SPECS, build_fa, build_v5s, oracle_fa_heads, rel_err, v5s_cfg
+from oracle import nets as ON
+from oracle import postproc as O
+from yolo_amd import _ffi, engine
+from yolo_amd.synthetic import _gen, images, init_deterministic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {"fp32": 1e-3, "bf16": 2e-2}
+
+
+@pytest.fixture(autouse=True)
+def _reset_compute():
+    yield
+    engine.set_compute_dtype(None)
+
+
+# ---- G5 blocks -------------------------------------------------------------------------------------------------
+def _block(tag):
+    import torch.nn as nn
+    from yolo_amd.models import common as C
+    from yolo_amd.utils import moduleUtils as A
+    from yolo_amd.yolov5_official import modules as B
+    table = {
+        "b_conv3s2": lambda: B.Conv(16, 32, 3, 2), "b_bottleneck": lambda: B.Bottleneck(32, 32),
+        "b_c3": lambda: B.C3(32, 32, n=2), "b_c3_noshortcut": lambda: B.C3(32, 16, n=1, shortcut=False),
+        "b_bottleneckcsp": lambda: B.BottleneckCSP(32, 32, n=2), "b_spp": lambda: B.SPP(32, 32),
+        "b_focus": lambda: B.Focus(3, 16, 3), "b_common_conv": lambda: C.Conv(16, 32, 3, 1),
+        "a_conv": lambda: A.Conv(16, 32, k=3, p=1, s=2), "a_resblock": lambda: A.resblock(32, nblocks=2),
+        "a_cspstage": lambda: A.CSPStage(32, n=2),
+        "a_cspbottleneck": lambda: A.CSPBottleneck(32, 32, n=2, shortcut=False),
+        "a_bottleneck": lambda: A.Bottleneck(32, 32),
+    }
+    blk = table[tag]()
+    init_deterministic(blk, seed=5)
+    if tag.startswith("b_") and tag != "b_common_conv":
+        for m in blk.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eps = 1e-3
+    return blk.eval()
+
+
+BLOCKS = ["b_conv3s2", "b_bottleneck", "b_c3", "b_c3_noshortcut", "b_bottleneckcsp", "b_spp", "b_focus",
+          "b_common_conv", "a_conv", "a_resblock", "a_cspstage", "a_cspbottleneck", "a_bottleneck"]
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", BLOCKS)
+def test_block_golden(golden, compute, tag):
+    g = golden("g5_" + tag)
+    blk = _block(tag).to(DEV)
+    x = torch.from_numpy(g["x"])
+    gr = engine.Graph(DEV, compute)
+    if tag == "b_focus":   # as first layer: slicing folded into the layout kernel
+        y = blk.conv.lower(gr, gr.input_nchw(*x.shape, focus=True))
+    else:
+        y = engine.lower_any(gr, blk, gr.input_nchw(*x.shape))
+    gr.to_nchw(y, "y")
+    out = gr.finalize().run(x.to(DEV))["y"].float().cpu().numpy()
+    assert out.shape == g["y"].shape
+    assert rel_err(out, g["y"]) < TOL[compute], tag
+    if tag == "b_c3":   # concat must have been resolved by redirection, not by copy kernels
+        assert not any(k == "copy" for k, _ in gr.ops)
+
+
+# ---- YOLOv5s ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("nc", [80, 20])
+def test_v5s_small_golden(golden, compute, nc):
+    g = golden(f"g6_v5s_nc{nc}_64")
+    engine.set_compute_dtype(compute)
+    m = build_v5s(nc).to(DEV)
+    x = images(2, 64, seed=64).to(DEV)
+    with torch.no_grad():
+        z, xs = m(x)
+    assert z.shape == g["z"].shape and z.dtype == torch.float32
+    tol = TOL[compute] if compute == "fp32" else 5e-2
+    for i in range(3):
+        assert tuple(xs[i].shape) == g[f"x{i}"].shape
+        assert rel_err(xs[i].cpu().numpy(), g[f"x{i}"]) < tol, f"head {i}"
+    zr = g["z"]
+    assert rel_err(z[..., 4:].cpu().numpy(), zr[..., 4:]) < tol          # probabilities
+    assert rel_err(z[..., :4].cpu().numpy(), zr[..., :4]) < tol          # boxes (pixels, scale = image size)
+    # decode consistency: z is exactly the decode of the returned raw maps
+    z2, _ = O.detect_decode([t.permute(0, 1, 4, 2, 3).reshape(t.shape[0], -1, t.shape[2], t.shape[3]).cpu().numpy() for t in xs],
+                            g["stride"], g["anchor_grid"].reshape(3, 3, 2), 3, nc + 5)
+    np.testing.assert_allclose(z.cpu().numpy(), z2, rtol=3e-6, atol=3e-6)
+
+
+def test_v5s_attributes_and_state_dict(golden):
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g8_structure.json")) as fh:
+        ref = json.load(fh)
+    m = build_v5s(80)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref["yolov5s_nc80"]
+    assert m.save == ref["yolov5s_nc80_extra"]["save"] and m.stride.tolist() == [8.0, 16.0, 32.0]
+    det = m.model[-1]
+    assert (det.nl, det.na, det.nc, det.no) == (3, 3, 80, 85) and m.names[79] == "79"
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_v5s_640_samples(golden, compute):
+    g = golden("g6_v5s_nc80_640")
+    engine.set_compute_dtype(compute)
+    m = build_v5s(80).to(DEV)
+    with torch.no_grad():
+        z, xs = m(images(1, 640, seed=640).to(DEV))
+    step = int(g["step"])
+    tol = 1e-3 if compute == "fp32" else 5e-2
+    for i in range(3):
+        got = xs[i].contiguous().cpu().numpy().reshape(-1)[::step]
+        assert rel_err(got, g[f"head_sample{i}"]) < tol
+    zs = z.cpu().numpy().reshape(-1)[::step]
+    assert rel_err(zs, g["z_sample"]) < tol
+    if compute == "fp32":
+        assert abs(float(z.double().sum()) - float(g["z_sum"])) / abs(float(g["z_sum"])) < 1e-4
+
+
+def test_v5s_compat_detect_golden(golden):
+    g = golden("g6_v5s_compat_nc20_64")
+    engine.set_compute_dtype("fp32")
+    m = build_v5s(20, compat=True).to(DEV)
+    with torch.no_grad():
+        z, _ = m(images(1, 64, seed=65).to(DEV))
+    assert rel_err(z.cpu().numpy(), g["z"]) < 1e-3
+
+
+def test_v5s_batch_consistency_and_replan():
+    """Same image in different batch positions / batch sizes gives the same rows; reloading weights re-plans."""
+    engine.set_compute_dtype("fp32")
+    m = build_v5s(20).to(DEV)
+    x = images(3, 96, seed=3).to(DEV)
+    with torch.no_grad():
+        z3, _ = m(x)
+        z1, _ = m(x[1:2])
+    assert torch.equal(z3[1], z1[0])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    init_deterministic(m, seed=1, head_convs=list(m.model[-1].m))
+    with torch.no_grad():
+        zb, _ = m(x)
+    assert not torch.equal(zb, z3)
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        zc, _ = m(x)
+    assert torch.equal(zc, z3)
+
+
+def test_v5s_end_to_end_nms_vs_oracle():
+    """Model -> decode -> NMS on the GPU vs oracle network -> oracle decode -> oracle NMS (fp32):
+    same detections up to box tolerance (the conv stacks differ by rounding, so rows are matched, not memcmp'd)."""
+    from yolo_amd.yolov5_official.utils import non_max_suppression
+    engine.set_compute_dtype("fp32")
+    m = build_v5s(20)
+    x = images(2, 128, seed=12)
+    with torch.no_grad():
+        heads = ON.yolov5_heads(m.state_dict(), x, v5s_cfg())
+    det = m.model[-1]
+    z_ref, _ = O.detect_decode([h.numpy() for h in heads], det.stride.tolist(), det.anchor_grid.view(3, 3, 2).numpy(), 3, 25)
+    ref = O.non_max_suppression(z_ref, 0.25, 0.45)
+    m = m.to(DEV)
+    with torch.no_grad():
+        out = non_max_suppression(m(x.to(DEV))[0], 0.25, 0.45)
+    for r, o in zip(ref, out):
+        o = o.cpu().numpy()
+        assert abs(len(o) - len(r)) <= max(1, len(r) // 50)
+        n = min(len(o), len(r))
+        if n:
+            matched = sum(1 for row in r if (np.abs(o[:, :4] - row[:4]).max(1) < 0.05).any())
+            assert matched >= len(r) - max(1, len(r) // 50)
+
+
+# ---- v2 / v3 / v4 detectors -----------------------------------------------------------------------------------------
+FA_CASES = [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v2d19", 416), ("v3spp", 128), ("v3", 128), ("v4", 128)]
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag,size", FA_CASES)
+def test_family_a_heads_golden(golden, compute, tag, size):
+    g = golden(f"g6_{tag}_{size}")
+    engine.set_compute_dtype(compute)
+    net = build_fa(tag, size).to(DEV)
+    x = images(1, size, seed=int(g["x_seed"]), kind="randn").to(DEV)
+    heads = net.head_maps(x)
+    tol = 1e-3 if compute == "fp32" else 5e-2
+    for h, name in zip(heads, FA_SPECS[tag][3]):
+        assert tuple(h.shape) == g["head_" + name].shape
+        assert rel_err(h.cpu().numpy(), g["head_" + name]) < tol, name
+
+
+@pytest.mark.parametrize("tag,size", [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v2d19", 416), ("v3spp", 128),
+                                      ("v3", 128), ("v4", 128)])
+def test_family_a_detections(golden, tag, size):
+    """forward() contract: numpy (bboxes [K,4] f32, scores [K] f32, cls [K] i64) of image 0 in box-index order.
+    With random weights the class softmax is nearly flat, so the argmax class (hence the per-class NMS
+    partition) flips under fp32 rounding of the head maps; the end-to-end check is therefore split the way
+    the parity bar is stated: (a) decoded boxes / scores within tolerance of the reference's, (b) the kept set
+    bit-exact against the oracle fed the SAME decoded boxes."""
+    g = golden(f"g6_{tag}_{size}")
+    engine.set_compute_dtype("fp32")
+    net = build_fa(tag, size).to(DEV)
+    x = images(1, size, seed=int(g["x_seed"]), kind="randn").to(DEV)
+    boxes, scores = net.decode_batch(x)
+    # saturated boxes (exp overflow -> clamp) are compared through the clamp, so absolute tolerance on [0,1]
+    np.testing.assert_allclose(boxes[0].cpu().numpy(), g["pre_bboxes"], atol=2e-3, rtol=0)
+    np.testing.assert_allclose(scores[0].cpu().numpy(), g["pre_scores"], atol=2e-3, rtol=2e-3)
+    bb, sc, cl = net(x)
+    assert bb.dtype == np.float32 and sc.dtype == np.float32 and cl.dtype == np.int64
+    rb, rs, rc = O.postprocess(boxes[0].cpu().numpy(), scores[0].cpu().numpy(), net.conf_thresh, 20, net.nms_thresh)
+    best = scores[0].max(1).values.cpu().numpy()
+    if len(np.unique(best)) == len(best):
+        np.testing.assert_array_equal(bb, rb)
+        np.testing.assert_array_equal(sc, rs)
+        np.testing.assert_array_equal(cl, rc)
+    else:   # exact score ties (saturated 1.0): same tie rule on both sides here, still exact
+        np.testing.assert_array_equal(bb, rb)
+        np.testing.assert_array_equal(cl, rc)
+
+
+@pytest.mark.parametrize("tag,size", [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v3spp", 128), ("v3", 128), ("v4", 128)])
+def test_family_a_nms_on_recorded_boxes(golden, tag, size):
+    """The reference's own (bboxes, scores) -> its own kept detections, through ydet_nms_perclass: exact."""
+    from yolo_amd import ops
+    g = golden(f"g6_{tag}_{size}")
+    best = g["pre_scores"].max(1)
+    if len(np.unique(best)) != len(best):
+        pytest.skip("recorded scores contain exact ties: the reference's visiting order is implementation-defined")
+    keep, cls, sc = ops.nms_perclass(torch.from_numpy(g["pre_bboxes"]).to(DEV)[None],
+                                     torch.from_numpy(g["pre_scores"]).to(DEV)[None], 0.001, 0.5)
+    k = keep[0].bool().cpu().numpy()
+    np.testing.assert_array_equal(g["pre_bboxes"][k], g["out_bboxes"])
+    np.testing.assert_array_equal(sc[0].cpu().numpy()[k], g["out_scores"])
+    np.testing.assert_array_equal(cls[0].cpu().numpy()[k], g["out_cls"])
+
+
+def test_family_a_batched_matches_single():
+    engine.set_compute_dtype("fp32")
+    net = build_fa("v3tiny", 128).to(DEV)
+    x = images(3, 128, seed=5, kind="randn").to(DEV)
+    boxes, keep, cls, best = net.detect_batch(x)
+    b1, k1, c1, s1 = net.detect_batch(x[2:3])
+    assert torch.equal(boxes[2], b1[0]) and torch.equal(keep[2], k1[0]) and torch.equal(cls[2], c1[0])
+    bb, sc, cl = net(x)   # image 0 only
+    k0 = keep[0].bool()
+    np.testing.assert_array_equal(bb, boxes[0][k0].cpu().numpy())
+
+
+def test_v3spp_608_samples(golden):
+    g = golden("g6_v3spp_608")
+    engine.set_compute_dtype("fp32")
+    net = build_fa("v3spp", 608).to(DEV)
+    heads = net.head_maps(images(1, 608, seed=608, kind="randn").to(DEV))
+    step = int(g["step"])
+    for h, name in zip(heads, ["pred_1", "pred_2", "pred_3"]):
+        assert rel_err(h.contiguous().cpu().numpy().reshape(-1)[::step], g["head_" + name]) < 1e-3
+
+
+def test_errors_are_loud():
+    net = build_fa("v3tiny", 64)
+    with pytest.raises(RuntimeError):
+        net(images(1, 64, kind="randn"))          # CPU tensor in inference: no silent CPU path
+    net.trainable = True
+    with pytest.raises(NotImplementedError):
+        net(images(1, 64, kind="randn").to(DEV))
+    from yolo_amd.yolov5_official.utils import non_max_suppression
+    with pytest.raises(RuntimeError):
+        non_max_suppression(torch.zeros(1, 10, 85))

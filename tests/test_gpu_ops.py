@@ -1,0 +1,336 @@
+"""GPU parity tests of the individual libydet.so operators, called through the C ABI (ctypes).
+
+Bars: index / integer results bit-exact against the oracle and the golden vectors; float32 decode within a
+few ulp-level tolerances (device vs host exp); convolution within 1e-3 (fp32 path) / 2e-2 (bf16 path) of a
+plain PyTorch fp32 reference, relative to the largest reference magnitude.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from helpers import rel_err
+from oracle import postproc as O
+from yolo_amd import _ffi, engine, ops
+from yolo_amd.synthetic import _gen, clustered_predictions
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(t):  # NCHW numpy/torch -> NHWC CUDA fp32 tensor
+    return torch.as_tensor(t).permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+# ---- decode ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,transposed", [("official", False), ("compat", True)])
+@pytest.mark.parametrize("nc", [3, 80])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_v5_golden(golden, tag, transposed, nc, dtype):
+    g = golden(f"g1_decode_{tag}_nc{nc}")
+    raws = [g["raw0"], g["raw1"], g["raw2"]]
+    heads = [nhwc(r).to(dtype) for r in raws]
+    z = ops.decode_v5(heads, g["stride"].tolist(), g["anchor_grid"].reshape(3, -1).tolist(), 3, nc + 5, transposed)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(z.cpu().numpy(), g["z"], rtol=3e-6, atol=2e-6)
+    else:  # bf16 heads: compare with the oracle fed the same rounded inputs
+        ref, _ = O.detect_decode([h.float().permute(0, 3, 1, 2).cpu().numpy() for h in heads], g["stride"],
+                                 g["anchor_grid"], 3, nc + 5, transposed)
+        np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=3e-6, atol=2e-6)
+
+
+def test_decode_v5_padded_ld():
+    """Head buffers with a padded channel stride (ld 256 for 255 channels) decode like dense ones."""
+    g = _gen(3, "ld")
+    raw = [torch.randn(2, 255, s, s, generator=g) for s in (8, 4, 2)]
+    dense = [nhwc(r) for r in raw]
+    padded = []
+    for d in dense:
+        buf = torch.zeros(*d.shape[:3], 256, device=DEV)
+        buf[..., :255] = d
+        padded.append(buf[..., :255])
+    strides, anchors = [8., 16., 32.], [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+    a = ops.decode_v5(dense, strides, anchors, 3, 85)
+    b = ops.decode_v5(padded, strides, anchors, 3, 85)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tag,size,v2", [("v3tiny", 64, False), ("v3tiny", 416, False), ("v2d19", 128, True),
+                                         ("v2d19", 416, True), ("v3spp", 128, True), ("v3", 128, False),
+                                         ("v4", 128, True)])
+def test_decode_v2v3_golden(golden, tag, size, v2):
+    from helpers import FA_SPECS, build_fa
+    g = golden(f"g6_{tag}_{size}")
+    net = build_fa(tag, size)
+    heads = [nhwc(g["head_" + h]) for h in FA_SPECS[tag][3]]
+    boxes, scores = ops.decode_v2v3(heads, net._level_anchors(), net.num_anchors, 20, 0 if v2 else 1, float(size))
+    np.testing.assert_allclose(boxes[0].cpu().numpy(), g["pre_bboxes"], rtol=2e-5, atol=3e-6)
+    np.testing.assert_allclose(scores[0].cpu().numpy(), g["pre_scores"], rtol=2e-5, atol=1e-7)
+
+
+# ---- YOLOv5 NMS -------------------------------------------------------------------------------------------------
+def _g4_pred(g):
+    if "pred" in g:
+        return torch.from_numpy(g["pred"])
+    n, nb, no, pct = [int(v) for v in g["pred_args"]]
+    return clustered_predictions(n, nb, no - 5, seed=int(g["pred_seed"]), obj_pass=pct / 100.0)
+
+
+def _check_nms(pred, out_list, **kw):
+    det, cnt = ops.nms_v5(pred.to(DEV), kw.get("conf_thres", 0.25), kw.get("iou_thres", 0.45),
+                          multi_label=kw.get("multi_label", False), agnostic=kw.get("agnostic", False),
+                          max_det=kw.get("max_det", 300), classes=kw.get("classes"))
+    det, cnt = det.cpu().numpy(), cnt.cpu().numpy()
+    for i, ref in enumerate(out_list):
+        assert cnt[i] == len(ref), f"image {i}: {cnt[i]} detections, expected {len(ref)}"
+        np.testing.assert_array_equal(det[i, : cnt[i]], ref)   # bit-exact rows, same order
+        assert not det[i, cnt[i]:].any()
+
+
+@pytest.mark.parametrize("tag", ["small_ml", "small_best", "small_agnostic", "few", "big_ml", "big_best"])
+def test_nms_v5_golden(golden, tag):
+    g = golden(f"g4_nms_{tag}")
+    kw = json.loads(str(g["kw"]))
+    _check_nms(_g4_pred(g), [g[f"out{i}"] for i in range(int(g["n_img"]))], **kw)
+
+
+@pytest.mark.parametrize("case", ["ties_all_equal", "ties_threshold_bin", "empty", "one", "classes", "nan_scores"])
+def test_nms_v5_edge_cases(case):
+    g = _gen(11, case)
+    kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    if case == "ties_all_equal":   # every candidate has the same score: exact top-k path, index order decides
+        pred = torch.zeros(2, 3000, 9)
+        pred[..., :2] = torch.rand(2, 3000, 2, generator=g) * 600
+        pred[..., 2:4] = 30.0
+        pred[..., 4] = 0.5
+        pred[..., 5:] = 0.5
+    elif case == "ties_threshold_bin":   # > 4096 candidates inside one histogram bin around the cut
+        pred = clustered_predictions(2, 6000, 4, seed=9, obj_pass=1.0)
+        pred[..., 4] = 0.75
+        pred[..., 5:] = 0.5 + torch.rand(2, 6000, 4, generator=g) * 1e-4
+    elif case == "empty":
+        pred = clustered_predictions(3, 500, 4, seed=3)
+        pred[..., 4] = 0.0005
+    elif case == "one":
+        pred = clustered_predictions(2, 64, 1, seed=4, obj_pass=0.5)   # nc == 1 disables multi_label
+    elif case == "classes":
+        pred = clustered_predictions(2, 800, 6, seed=5)
+        kw = dict(conf_thres=0.2, iou_thres=0.45, classes=[1, 4])
+    else:   # NaN / inf inputs must not hang or crash; compared to the oracle on the finite image only
+        pred = clustered_predictions(2, 400, 3, seed=6)
+        pred[1, ::7, 4] = float("nan")
+        ref = O.non_max_suppression(pred[:1].numpy(), **kw)
+        det, cnt = ops.nms_v5(pred.to(DEV), 0.001, 0.6, multi_label=True)
+        np.testing.assert_array_equal(det[0, : int(cnt[0])].cpu().numpy(), ref[0])
+        return
+    ref = O.non_max_suppression(pred.numpy(), **kw)
+    _check_nms(pred, ref, **kw)
+
+
+def test_nms_v5_full_size_properties():
+    """BASELINE size (64 x 25200 x 85): properties that do not need the oracle at full size --
+    idempotence on its own output, descending scores, count bound -- plus oracle equality on two images."""
+    pred = clustered_predictions(64, 25200, 80, seed=21, obj_pass=0.3)
+    det, cnt = ops.nms_v5(pred.to(DEV), 0.001, 0.6, multi_label=True)
+    det_h, cnt_h = det.cpu().numpy(), cnt.cpu().numpy()
+    assert (cnt_h <= 300).all() and (cnt_h > 0).all()
+    for i in range(64):
+        s = det_h[i, : cnt_h[i], 4]
+        assert (np.diff(s) <= 0).all()
+    ref = O.non_max_suppression(pred[:2].numpy(), 0.001, 0.6, multi_label=True)
+    for i in range(2):
+        np.testing.assert_array_equal(det_h[i, : cnt_h[i]], ref[i])
+    # idempotence: feed the survivors back as single-class-score predictions; nothing more is removed
+    again = torch.zeros(64, 300, 85)
+    xyxy = torch.from_numpy(det_h[..., :4])
+    again[..., 0] = (xyxy[..., 0] + xyxy[..., 2]) / 2
+    again[..., 1] = (xyxy[..., 1] + xyxy[..., 3]) / 2
+    again[..., 2] = xyxy[..., 2] - xyxy[..., 0]
+    again[..., 3] = xyxy[..., 3] - xyxy[..., 1]
+    again[..., 4] = 1.0
+    cls = torch.from_numpy(det_h[..., 5]).long()
+    again.scatter_(2, (cls + 5).unsqueeze(-1), torch.from_numpy(det_h[..., 4:5]))
+    det2, cnt2 = ops.nms_v5(again.to(DEV), 0.0009, 0.6, multi_label=True)
+    # xywh round trip moves coordinates by an ulp, so allow the rare boundary flip
+    assert (cnt2.cpu().numpy() >= cnt_h - 1).all() and (cnt2.cpu().numpy() <= cnt_h).all()
+
+
+# ---- family-A NMS -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_nms_perclass_golden(golden, case):
+    g = golden(f"g3_postprocess_{case}")
+    bb, sc = torch.from_numpy(g["bb"]).to(DEV)[None], torch.from_numpy(g["scores"]).to(DEV)[None]
+    keep, cls, best = ops.nms_perclass(bb, sc, float(g["conf"]), float(g["thr"]))
+    k = keep[0].bool().cpu().numpy()
+    np.testing.assert_array_equal(g["bb"][k], g["out_bb"])
+    np.testing.assert_array_equal(best[0].cpu().numpy()[k], g["out_scores"])
+    np.testing.assert_array_equal(cls[0].cpu().numpy()[k].astype(np.int64), g["out_cls"])
+
+
+def test_nms_perclass_batch_and_wrappers(golden):
+    from yolo_amd.utils import utils as fa
+    gs = [golden(f"g3_postprocess_{c}") for c in (0, 1)]
+    n = 600
+    bb = torch.stack([torch.from_numpy(g["bb"][:n]) for g in gs]).to(DEV)
+    sc = torch.stack([torch.from_numpy(g["scores"][:n]) for g in gs]).to(DEV)
+    keep, cls, best = ops.nms_perclass(bb, sc, 0.001, 0.5)
+    for i, g in enumerate(gs):
+        rb, rs, rc = O.postprocess(g["bb"][:n], g["scores"][:n], 0.001, 20, 0.5)
+        k = keep[i].bool().cpu().numpy()
+        np.testing.assert_array_equal(g["bb"][:n][k], rb)
+        np.testing.assert_array_equal(cls[i].cpu().numpy()[k], rc)
+    # numpy-in / numpy-out API of the reference
+    g = gs[0]
+    ob, osc, oc = fa.postprocess(g["bb"], g["scores"], float(g["conf"]), int(g["nc"]), float(g["thr"]))
+    np.testing.assert_array_equal(ob, g["out_bb"])
+    np.testing.assert_array_equal(oc, g["out_cls"])
+    assert oc.dtype == np.int64 and ob.dtype == np.float32
+    assert fa.nms(g["bb"], g["scores"][:, 0], float(g["thr"])) == [int(i) for i in g["nms_keep_class0_scores"]]
+
+
+def test_nms_perclass_single_class_large():
+    """All boxes in one class (longest serial chain) against the oracle."""
+    g = _gen(5, "one-class")
+    n = 3000
+    c = torch.rand(n, 2, generator=g)
+    wh = torch.rand(n, 2, generator=g) * 0.1 + 0.01
+    bb = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 1)
+    sc = torch.rand(n, 1, generator=g)
+    keep, _, _ = ops.nms_perclass(bb.to(DEV)[None], sc.to(DEV)[None], 0.0, 0.5)
+    ref = sorted(O.nms_numpy(bb.numpy(), sc[:, 0].numpy(), 0.5))
+    assert np.nonzero(keep[0].cpu().numpy())[0].tolist() == ref
+
+
+def test_box_iou(golden):
+    g = golden("g7_v5_metrics")
+    iou = ops.box_iou(torch.from_numpy(g["box1"]).to(DEV), torch.from_numpy(g["box2"]).to(DEV))
+    np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=1e-6, atol=1e-7)
+
+
+# ---- pooling / resampling / layout against torch fp32 ------------------------------------------------------------
+def _run_graph(build, *xs, compute="fp32"):
+    g = engine.Graph(DEV, compute)
+    build(g, [g.input_nchw(*x.shape) for x in xs])
+    return g.finalize().run(*[x.to(DEV) for x in xs])
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 0.0), ("bf16", 8e-3)])
+@pytest.mark.parametrize("C", [8, 24, 64])
+def test_spatial_ops(compute, tol, C):
+    g = _gen(2, f"sp{C}")
+    x = torch.randn(2, C, 12, 10, generator=g)
+    xs = torch.randn(2, C, 19, 19, generator=g)
+    if compute == "bf16":
+        x, xs = x.bfloat16().float(), xs.bfloat16().float()
+
+    def build(gr, ins):
+        t, ts = ins
+        gr.to_nchw(gr.maxpool2(t), "pool")
+        gr.to_nchw(gr.maxpool2s1(t), "pools1")
+        gr.to_nchw(gr.upsample2x(t, 0), "near")
+        gr.to_nchw(gr.upsample2x(t, 1), "bil")
+        gr.to_nchw(gr.space_to_depth(t, 0), "reorg")
+        gr.to_nchw(gr.space_to_depth(t, 1), "focus")
+        gr.to_nchw(gr.spp(ts), "spp")
+        gr.to_nchw(gr.cat([gr.maxpool2(t), gr.maxpool2(t)]), "cat")
+
+    out = _run_graph(build, x, xs, compute=compute)
+    ref = {
+        "pool": F.max_pool2d(x, 2, 2),
+        "pools1": F.max_pool2d(F.pad(x, (0, 1, 0, 1)), 2, 1),
+        "near": F.interpolate(x, scale_factor=2, mode="nearest"),
+        "bil": F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True),
+        "focus": torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1),
+        "spp": torch.cat([xs] + [F.max_pool2d(xs, k, 1, k // 2) for k in (5, 9, 13)], 1),
+    }
+    b, c, h, w = x.shape
+    ref["reorg"] = x.view(b, c, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(b, 4 * c, h // 2, w // 2)
+    ref["cat"] = torch.cat([ref["pool"], ref["pool"]], 1)
+    for k, r in ref.items():
+        got = out[k].float().cpu()
+        assert got.shape == r.shape, k
+        if k == "bil":
+            assert rel_err(got, r) <= max(tol, 2e-6), k
+        else:
+            assert rel_err(got, r) <= tol, k
+
+
+def test_golden_pool_and_upsample(golden):
+    for name, fn in (("g5_a_upsample_bilinear", lambda gr, t: gr.upsample2x(t, 1)),
+                     ("g5_a_zeropad_pool", lambda gr, t: gr.maxpool2s1(t)),
+                     ("g5_a_reorg", lambda gr, t: gr.space_to_depth(t, 0)),
+                     ("g5_a_spp", lambda gr, t: gr.spp(t))):
+        g = golden(name)
+        x = torch.from_numpy(g["x"])
+        out = _run_graph(lambda gr, ins: gr.to_nchw(fn(gr, ins[0]), "y"), x)
+        np.testing.assert_allclose(out["y"].cpu().numpy(), g["y"], rtol=2e-6, atol=2e-6, err_msg=name)
+
+
+# ---- convolution against torch fp32 -------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, act, residual
+    (2, 16, 16, 16, 32, 3, 1, 1, "silu", None),
+    (2, 16, 16, 32, 32, 3, 1, 1, "silu", "after"),
+    (1, 20, 20, 64, 64, 1, 1, 0, "leaky", None),
+    (2, 17, 13, 32, 64, 3, 2, 1, "leaky", None),        # odd sizes, stride 2
+    (2, 16, 16, 8, 16, 3, 1, 1, "leaky", None),          # narrow
+    (1, 13, 13, 128, 255, 1, 1, 0, "none", None),        # ragged head conv
+    (1, 13, 13, 64, 75, 1, 1, 0, "none", None),
+    (3, 9, 9, 256, 128, 3, 1, 1, "leaky", "before"),
+    (1, 26, 26, 512, 256, 1, 1, 0, "leaky", None),       # deep K
+    (1, 8, 8, 24, 160, 3, 1, 1, "silu", None),           # Cin not a multiple of the K-step
+    (2, 40, 40, 64, 128, 3, 2, 1, "silu", None),
+    (1, 6, 6, 1024, 512, 1, 1, 0, "silu", None),
+    (2, 11, 11, 40, 40, 5, 1, 2, "none", None),          # 5x5 kernel
+]
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_against_torch(compute, tol, case):
+    N, H, W, Cin, Cout, k, s, p, act, resk = case
+    g = _gen(7, f"conv{case}")
+    conv = nn.Conv2d(Cin, Cout, k, s, p, bias=True)
+    bn = nn.BatchNorm2d(Cout) if act != "none" else None
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+        conv.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        if bn is not None:
+            bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+            bn.eval()
+    x = torch.randn(N, Cin, H, W, generator=g)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    r = torch.randn(N, Cout, Ho, Wo, generator=g) if resk else None
+    actf = {"silu": F.silu, "leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t}[act]
+    with torch.no_grad():
+        y = conv(x)
+        if bn is not None:
+            y = bn(y)
+        ref = actf(y + r) if resk == "before" else (actf(y) + (r if resk else 0))
+    code = {"silu": _ffi.ACT_SILU, "leaky": _ffi.ACT_LEAKY, "none": _ffi.ACT_NONE}[act]
+
+    def build(gr, ins):
+        res = ins[1] if resk else None
+        mode = {None: _ffi.RES_NONE, "after": _ffi.RES_AFTER_ACT, "before": _ffi.RES_BEFORE_ACT}[resk]
+        out = gr.conv(ins[0], conv, bn, act=code, slope=0.1, res=res, res_mode=mode,
+                      out_dtype=_ffi.F32 if act == "none" else None)
+        gr.to_nchw(out, "y")
+
+    out = _run_graph(build, *([x, r] if resk else [x]), compute=compute)
+    assert out["y"].shape == ref.shape
+    assert rel_err(out["y"].float().cpu(), ref) < tol
+
+
+def test_conv_argument_validation():
+    lib = _ffi.lib()
+    d = _ffi.ConvDesc()
+    rc = lib.ydet_conv2d_nhwc(d, None)
+    assert rc == -1 and b"null" in lib.ydet_last_error()
+    with pytest.raises(RuntimeError):
+        _ffi.check(rc, "conv")

@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void decode_v5_kernel(const V5Args a) {
             const int row = cell / a.nx[l], col = cell - row * a.nx[l];
             d.level = l;
             d.src = ((long long)((long long)n * a.ny[l] + row) * a.nx[l] + col) * a.ld[l] + (long long)an * a.no;
-            d.gx = a.transposed ? (float)row : (float)col;
-            d.gy = a.transposed ? (float)col : (float)row;
+            // "transposed": the np.meshgrid(arange(ny), arange(nx)) table of shape (nx, ny) re-read as
+            // (ny, nx): flat cell f holds (f / ny, f % ny) -- (row, col) on square maps.
+            d.gx = a.transposed ? (float)(cell / a.ny[l]) : (float)col;
+            d.gy = a.transposed ? (float)(cell % a.ny[l]) : (float)row;
             d.stride = a.stride[l];
             d.aw = a.anchor[l][2 * an];
             d.ah = a.anchor[l][2 * an + 1];
@@ -127,8 +129,9 @@ __global__ __launch_bounds__(256) void decode_fa_kernel(const FAArgs a) {
     for (int c = 0; c < a.nc; ++c) sc[c] = expf(to_f32(cl[c]) - mx) / sum * conf;
 
     const T* t = px + a.A * (1 + a.nc) + an * 4;
-    const float gx = a.transposed ? (float)row : (float)col;
-    const float gy = a.transposed ? (float)col : (float)row;
+    // reference grid: np.meshgrid(arange(H), arange(W)) stacked and flattened: cell k holds (k / H, k % H)
+    const float gx = a.transposed ? (float)(cell / a.H[l]) : (float)col;
+    const float gy = a.transposed ? (float)(cell % a.H[l]) : (float)row;
     const float aw = a.anchor[l][2 * an], ah = a.anchor[l][2 * an + 1];
     float cx, cy, w, h;
     if (a.mode == 0) {  // xywh_to_xxyy: everything scaled by mult

@@ -1,6 +1,8 @@
 // Error reporting and the launch-list executor of libydet.so.
 #include <string.h>
 
+#include <new>
+
 #include "ydet_internal.h"
 
 int ydet_launch_slice(int op_kind, const ydet_slice_desc* d, int mode, hipStream_t stream);
@@ -27,12 +29,70 @@ void clear_error() { g_err[0] = 0; }
 extern "C" const char* ydet_last_error(void) { return ydet::g_err; }
 extern "C" int ydet_abi_version(void) { return 1; }
 
+struct ydet_timer {
+    int n_marks;
+    hipEvent_t* ev;
+};
+
+extern "C" ydet_timer* ydet_timer_create(int n_marks) {
+    ydet::clear_error();
+    if (n_marks <= 0) { ydet::fail(YDET_ERR_ARG, "timer_create: n_marks=%d", n_marks); return nullptr; }
+    ydet_timer* t = new (std::nothrow) ydet_timer;
+    if (!t) { ydet::fail(YDET_ERR_LAUNCH, "timer_create: out of host memory"); return nullptr; }
+    t->n_marks = n_marks;
+    t->ev = new (std::nothrow) hipEvent_t[n_marks];
+    if (!t->ev) { delete t; ydet::fail(YDET_ERR_LAUNCH, "timer_create: out of host memory"); return nullptr; }
+    for (int i = 0; i < n_marks; ++i) {
+        if (hipEventCreate(&t->ev[i]) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(t->ev[j]);
+            delete[] t->ev;
+            delete t;
+            ydet::fail(YDET_ERR_LAUNCH, "timer_create: hipEventCreate failed");
+            return nullptr;
+        }
+    }
+    return t;
+}
+
+extern "C" void ydet_timer_destroy(ydet_timer* t) {
+    if (!t) return;
+    for (int i = 0; i < t->n_marks; ++i) (void)hipEventDestroy(t->ev[i]);
+    delete[] t->ev;
+    delete t;
+}
+
+extern "C" int ydet_timer_elapsed(ydet_timer* t, int first_mark, int n_intervals, float* ms) {
+    ydet::clear_error();
+    if (!t || !ms || first_mark < 0 || n_intervals < 0 || first_mark + n_intervals > t->n_marks - 1)
+        return ydet::fail(YDET_ERR_ARG, "timer_elapsed: bad range");
+    for (int i = 0; i < n_intervals; ++i) {
+        hipError_t e = hipEventElapsedTime(&ms[i], t->ev[first_mark + i], t->ev[first_mark + i + 1]);
+        if (e != hipSuccess) return ydet::fail(YDET_ERR_LAUNCH, "timer_elapsed: %s", hipGetErrorString(e));
+    }
+    return YDET_OK;
+}
+
+static int run_ops_impl(const ydet_op* ops, int n_ops, hipStream_t s, ydet_timer* timer, int first_mark);
+
 // Runs a pre-planned forward pass: every op is validated and enqueued on `stream` in order; the
 // first failure stops the walk and is reported with the op index.
 extern "C" int ydet_run_ops(const ydet_op* ops, int n_ops, void* stream) {
     ydet::clear_error();
+    return run_ops_impl(ops, n_ops, ydet::as_stream(stream), nullptr, 0);
+}
+
+extern "C" int ydet_run_ops_timed(const ydet_op* ops, int n_ops, void* stream, ydet_timer* timer, int first_mark) {
+    ydet::clear_error();
+    if (!timer || first_mark < 0 || first_mark + n_ops + 1 > timer->n_marks)
+        return ydet::fail(YDET_ERR_ARG, "run_ops_timed: timer has %d marks, need %d..%d", timer ? timer->n_marks : 0,
+                          first_mark, first_mark + n_ops);
+    return run_ops_impl(ops, n_ops, ydet::as_stream(stream), timer, first_mark);
+}
+
+static int run_ops_impl(const ydet_op* ops, int n_ops, hipStream_t s, ydet_timer* timer, int first_mark) {
     if (n_ops < 0 || (n_ops > 0 && !ops)) return ydet::fail(YDET_ERR_ARG, "run_ops: bad op list");
-    hipStream_t s = ydet::as_stream(stream);
+    if (timer && hipEventRecord(timer->ev[first_mark], s) != hipSuccess)
+        return ydet::fail(YDET_ERR_LAUNCH, "run_ops: hipEventRecord failed");
     for (int i = 0; i < n_ops; ++i) {
         const ydet_op& op = ops[i];
         int rc;
@@ -61,6 +121,8 @@ extern "C" int ydet_run_ops(const ydet_op* ops, int n_ops, void* stream) {
             msg[sizeof(msg) - 1] = 0;
             return ydet::fail(rc, "run_ops: op %d of %d: %s", i, n_ops, msg);
         }
+        if (timer && hipEventRecord(timer->ev[first_mark + i + 1], s) != hipSuccess)
+            return ydet::fail(YDET_ERR_LAUNCH, "run_ops: hipEventRecord failed");
     }
     return YDET_OK;
 }

@@ -66,8 +66,9 @@ class T:
 class PackedConv:
     """Device-resident packed weights + bias of one (conv [+ BatchNorm]) for one input layout."""
 
-    def __init__(self, w, b, Cin, Cout, KH, KW, kp, cout_pad):
+    def __init__(self, w, b, Cin, Cout, KH, KW, kp, cout_pad, cin_real=None):
         self.w, self.b, self.Cin, self.Cout, self.KH, self.KW, self.kp, self.cout_pad = w, b, Cin, Cout, KH, KW, kp, cout_pad
+        self.cin_real = cin_real or Cin
 
 
 def pack_conv(conv, bn=None, bn_slice=None, cin_phys=None, dtype=_ffi.BF16, device=None):
@@ -106,7 +107,7 @@ def pack_conv(conv, bn=None, bn_slice=None, cin_phys=None, dtype=_ffi.BF16, devi
     wp[:Cout, :K] = w.reshape(Cout, K)
     bp = torch.zeros(cout_pad, device=device, dtype=torch.float32)
     bp[:Cout] = b
-    return PackedConv(wp.to(_TORCH_DT[dtype]).contiguous(), bp, cin_phys, Cout, KH, KW, kp, cout_pad)
+    return PackedConv(wp.to(_TORCH_DT[dtype]).contiguous(), bp, cin_phys, Cout, KH, KW, kp, cout_pad, cin_real=Cin)
 
 
 class Graph:
@@ -229,8 +230,10 @@ class Plan:
         self.patch_out = []       # (op index, field, storage) of external NHWC outputs
         self.nchw_out = []        # (op index, name, shape, dtype)
         self._ext_storages = [st for st in g.storages if st.external]
+        self.op_info = []         # per op: kind, label, algorithmic flops and bytes (measurement bookkeeping)
         for i, (kind, a) in enumerate(g.ops):
             op = self.ops[i]
+            self.op_info.append(_op_info(kind, a))
             if kind == "conv":
                 self._fill_conv(i, op, a)
             elif kind == "nchw2nhwc":
@@ -292,9 +295,10 @@ class Plan:
         d.act, d.slope, d.res_mode = a["act"], a["slope"], a["res_mode"]
         d.in_dtype, d.out_dtype = rx.dtype, ry.dtype
 
-    def run(self, *xs):
+    def run(self, *xs, timer=None, first_mark=0):
         """xs: the NCHW CUDA inputs (fp32 or bf16; other dtypes are converted to fp32), in the order
-        they were declared.  Returns {name: tensor} of the plan's outputs."""
+        they were declared.  Returns {name: tensor} of the plan's outputs.  `timer` (a ydet_timer handle):
+        record an event before the first and after every op into marks first_mark.. (see bench.py)."""
         lib = _ffi.lib()
         assert len(xs) == len(self.patch_in), f"plan takes {len(self.patch_in)} inputs"
         outs = {}
@@ -329,23 +333,72 @@ class Plan:
             self.ops[i].slice.y = t.data_ptr()
             outs[name] = t
         with torch.cuda.device(self.device):
-            _ffi.check(lib.ydet_run_ops(self.ops, len(self.ops), _ffi.current_stream()), "ydet_run_ops")
+            if timer is None:
+                _ffi.check(lib.ydet_run_ops(self.ops, len(self.ops), _ffi.current_stream()), "ydet_run_ops")
+            else:
+                _ffi.check(lib.ydet_run_ops_timed(self.ops, len(self.ops), _ffi.current_stream(), timer, first_mark),
+                           "ydet_run_ops_timed")
         for name, t in self.g.outputs.items():
             root, off = t.resolve()
             outs[name] = root.tensor[..., off:off + t.C]
         return outs
 
 
-class PlanCache:
-    """Per-model cache of plans keyed by (input shape, compute dtype); dropped when weights move."""
+def conv_tile(cout):
+    """Output tile (channels x pixels) the conv dispatcher picks; mirrors launch_dtype() in csrc/conv.hip."""
+    return (32, 256) if cout <= 32 else (64, 128) if cout <= 64 else (128, 128)
 
-    def __init__(self):
+
+def _op_info(kind, a):
+    esz = lambda t: 2 if t.dtype == _ffi.BF16 else 4
+    if kind == "conv":
+        x, y, pc = a["x"], a["y"], a["pc"]
+        bn, bm = conv_tile(pc.Cout)
+        one = pc.KH == 1 and pc.KW == 1 and a["pad"] == 0
+        flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.cin_real * pc.KH * pc.KW
+        nbytes = x.N * x.H * x.W * x.C * esz(x) + y.N * y.H * y.W * y.C * esz(y) + pc.Cout * pc.KH * pc.KW * x.C * esz(x)
+        if a["res"] is not None:
+            nbytes += y.N * y.H * y.W * y.C * esz(x)
+        return dict(kind="conv", label=f"conv_igemm<{bn}x{bm},{'1x1' if one else 'kxk'}>", flops=flops, bytes=nbytes,
+                    shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
+    if kind == "nchw2nhwc":
+        y = a["y"]
+        n = a["N"] * a["C"] * a["H"] * a["W"]
+        return dict(kind=kind, label=kind, flops=0.0, bytes=n * 4 + y.N * y.H * y.W * y.C * esz(y))
+    if kind == "nhwc2nchw":
+        x = a["x"]
+        n = x.N * x.H * x.W * x.C
+        return dict(kind=kind, label=kind, flops=0.0, bytes=n * esz(x) + n * 4)
+    x, y = a["x"], a["y"]
+    return dict(kind=kind, label=kind, flops=0.0,
+                bytes=x.N * x.H * x.W * x.C * esz(x) + y.N * y.H * y.W * y.C * esz(y))
+
+
+class PlanCache:
+    """Per-model cache of plans keyed by (input shape, compute dtype).  A plan holds folded / packed copies of
+    the weights, so the cache also remembers a version signature of the owning module's parameters and
+    buffers and drops every plan when any of them was modified in place (optimizer step, copy_, ...)."""
+
+    def __init__(self, owner=None):
         self.plans = {}
+        self.owner = owner
+        self.tensors = None
+        self.signature = None
 
     def clear(self):
         self.plans.clear()
+        self.tensors = None
+
+    def _sig(self):
+        if self.tensors is None:
+            self.tensors = list(self.owner.parameters()) + list(self.owner.buffers()) if self.owner is not None else []
+        return sum(t._version for t in self.tensors)
 
     def get(self, key, build):
+        sig = self._sig()
+        if sig != self.signature:
+            self.plans.clear()
+            self.signature = sig
         p = self.plans.get(key)
         if p is None:
             p = self.plans[key] = build()
@@ -377,7 +430,7 @@ class AcceleratedModule(torch.nn.Module):
     def _plans(self):
         pc = self.__dict__.get("_ydet_plan_cache")
         if pc is None:
-            pc = self.__dict__["_ydet_plan_cache"] = PlanCache()
+            pc = self.__dict__["_ydet_plan_cache"] = PlanCache(self)
         return pc
 
     def invalidate_plans(self):

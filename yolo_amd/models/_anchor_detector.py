@@ -33,16 +33,21 @@ class AnchorDetector(engine.AcceleratedModule):
     def detect_batch(self, x):
         """x [N,3,S,S] CUDA -> device tensors (boxes [N,n,4], keep [N,n] u8, cls [N,n] i32, score [N,n]).
         Image i's detections are boxes[i][keep[i]] etc., in box-index order."""
+        boxes, scores = self.decode_batch(x)
+        keep, cls, best = ops.nms_perclass(boxes, scores, self.conf_thresh, self.nms_thresh)
+        return boxes, keep, cls, best
+
+    @torch.no_grad()
+    def decode_batch(self, x):
+        """x [N,3,S,S] CUDA -> (boxes [N,n,4] normalised + clamped xyxy, scores [N,n,nc] = softmax(cls)*sigmoid(conf))
+        for every image: what the reference hands to postprocess() for image 0."""
         if not x.is_cuda:
             raise RuntimeError(f"{type(self).__name__}: inference runs on the GPU only (got a CPU tensor)")
         if self.training:
             raise RuntimeError(f"{type(self).__name__}: call .eval() first (BatchNorm is folded from running stats)")
-        heads = self.head_maps_nhwc(x)
-        boxes, scores = ops.decode_v2v3(heads, self._level_anchors(), self.num_anchors, self.num_classes,
-                                        mode=0 if self.decode_v2 else 1, input_size=float(self.input_size),
-                                        mult=self.box_multiplier, grid_transposed=True)
-        keep, cls, best = ops.nms_perclass(boxes, scores, self.conf_thresh, self.nms_thresh)
-        return boxes, keep, cls, best
+        return ops.decode_v2v3(self.head_maps_nhwc(x), self._level_anchors(), self.num_anchors, self.num_classes,
+                               mode=0 if self.decode_v2 else 1, input_size=float(self.input_size),
+                               mult=self.box_multiplier, grid_transposed=True)
 
     def head_maps_nhwc(self, x):
         """Raw prediction maps as fp32 NHWC views [N, H, W, A*(5+nc)], fine -> coarse."""

@@ -50,10 +50,13 @@ class Detect(nn.Module):
 
     # ---- stock-torch face ---------------------------------------------------------------------
     def _make_grid(self, nx=20, ny=20, use_gpu=False):
-        yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="ij")
-        if self.grid_transposed:  # stored x offset is the row index, y offset the column index
-            xv, yv = yv, xv
-        return torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()
+        if self.grid_transposed:
+            # np.meshgrid(arange(ny), arange(nx)) has shape (nx, ny); stacked and re-read as (ny, nx) the flat
+            # cell f holds (f // ny, f % ny), i.e. (row, col) on square maps
+            yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="xy")
+        else:
+            yv, xv = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="ij")
+        return torch.stack((xv, yv), 2).reshape(1, 1, ny, nx, 2).float()
 
     def forward(self, x):
         if not self.training and x[0].is_cuda:
@@ -92,7 +95,7 @@ class Detect(nn.Module):
     def _forward_hip(self, x):
         """Stand-alone call with CUDA NCHW feature maps."""
         key = tuple(tuple(t.shape) for t in x) + (engine.compute_dtype_for(self),)
-        cache = self.__dict__.setdefault("_ydet_plan_cache", engine.PlanCache())
+        cache = self.__dict__.setdefault("_ydet_plan_cache", engine.PlanCache(self))
 
         def build():
             g = engine.Graph(x[0].device, key[-1])
