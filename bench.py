@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--per-op", default=None, help="write a per-op timing table (tsv) to this path")
     args = ap.parse_args()
 
     import yolo_amd
@@ -127,6 +128,18 @@ def main():
         for i, info in enumerate(plan.op_info):
             d = per_label.setdefault(info["label"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d["ms"] += buf[i]; d["launches"] += 1; d["flops"] += info["flops"]; d["bytes"] += info["bytes"]
+    if args.per_op and rank == 0:
+        per_op = [0.0] * n_ops
+        for k in range(args.steps):
+            _ffi.check(lib.ydet_timer_elapsed(timer, k * (n_ops + 1), n_ops, buf), "ydet_timer_elapsed")
+            for i in range(n_ops):
+                per_op[i] += buf[i] / args.steps
+        with open(args.per_op, "w") as fh:
+            fh.write("op\tlabel\tshape(N,H,W,Cin,Cout,k,s)\tus\tTFLOP/s\tGB/s\n")
+            for i, info in enumerate(plan.op_info):
+                us = per_op[i] * 1e3
+                fh.write(f"{i}\t{info['label']}\t{info.get('shape', '')}\t{us:.1f}\t{info['flops'] / (us * 1e-6) / 1e12:.1f}\t"
+                         f"{info['bytes'] / (us * 1e-6) / 1e9:.0f}\n")
     lib.ydet_timer_destroy(timer)
     decode_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
     nms_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps

@@ -41,6 +41,8 @@ struct ConvArgs {
     int vec_store;    // 4-channel vector stores are legal
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ int chunk_swz(int g) { return (0x78 >> (2 * (g & 3))) & 3; }
 
 template <typename T>
@@ -158,13 +160,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
     }
 
-    uint4 wreg[WL], xreg[XL];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    u32x4 wreg[WL], xreg[XL];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
     auto load_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < WL; ++i) {
-            if (BN >= 64 || ld_row < BN) wreg[i] = *reinterpret_cast<const uint4*>(wptr[i]);
+            if (BN >= 64 || ld_row < BN) wreg[i] = *reinterpret_cast<const u32x4*>(wptr[i]);
             wptr[i] += BK * sizeof(TIN);
         }
 #pragma unroll
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 ok = xok[i] && kh < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 off = ((size_t)(hi * a.W + wi) * a.x_ld + kc) * sizeof(TIN);
             }
-            xreg[i] = ok ? *reinterpret_cast<const uint4*>(xbase[i] + off) : zero4;
+            xreg[i] = ok ? *reinterpret_cast<const u32x4*>(xbase[i] + off) : zero4;
         }
         // advance to the next K-step
         kc += BK;
@@ -195,9 +197,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         char* xs = ws + BN * 64;
 #pragma unroll
         for (int i = 0; i < WL; ++i)
-            if (BN >= 64 || ld_row < BN) *reinterpret_cast<uint4*>(ws + st_off + i * 64 * 64) = wreg[i];
+            if (BN >= 64 || ld_row < BN) *reinterpret_cast<u32x4*>(ws + st_off + i * 64 * 64) = wreg[i];
 #pragma unroll
-        for (int i = 0; i < XL; ++i) *reinterpret_cast<uint4*>(xs + st_off + i * 64 * 64) = xreg[i];
+        for (int i = 0; i < XL; ++i) *reinterpret_cast<u32x4*>(xs + st_off + i * 64 * 64) = xreg[i];
     };
 
     f32x4 acc[FN][FM];
