@@ -78,6 +78,9 @@ typedef struct {
     int32_t res_mode; /* ydet_res_mode */
     int32_t in_dtype; /* dtype of x, w and res */
     int32_t out_dtype;/* dtype of y */
+    int32_t cout_store; /* 0, or the number of channels written per pixel, Cout <= cout_store <= cout_pad:
+                           the extra channels are the zero rows of w (value act(0) = 0); lets a head with
+                           255 channels be stored as 256 with whole 16-byte pieces */
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 

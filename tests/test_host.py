@@ -1,0 +1,230 @@
+"""CPU-side checks of the product: the C ABI surface, the planner, the host-side metric code against the
+golden vectors, state_dict structure, and the 2-rank (gloo) data-parallel exchange.  No GPU needed."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FA_SPECS, ROOT, build_fa, build_v5s
+
+HEADER = os.path.join(ROOT, "include", "ydet.h")
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------------
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ydet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from yolo_amd import _ffi
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    assert sorted(_ffi.SYMBOLS) == declared, "the ctypes table and include/ydet.h disagree"
+    lib = _ffi.lib()   # dlopen + dlsym of every symbol; raises if one is missing
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ydet_abi_version() == 2
+    assert lib.ydet_last_error() == b""
+
+
+def test_ctypes_structs_match_header_layout():
+    """sizeof() of the ctypes mirrors against a C compile of the header (catches field drift)."""
+    from yolo_amd import _ffi
+    src = '#include <stdio.h>\n#include "ydet.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(ydet_conv_desc),' \
+          'sizeof(ydet_slice_desc), sizeof(ydet_v5_level), sizeof(ydet_fa_level), sizeof(ydet_op));return 0;}'
+    exe = os.path.join(ROOT, "build", "abi_sizes")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    sizes = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
+    import ctypes as C
+    assert sizes == [C.sizeof(_ffi.ConvDesc), C.sizeof(_ffi.SliceDesc), C.sizeof(_ffi.V5Level), C.sizeof(_ffi.FALevel),
+                     C.sizeof(_ffi.Op)]
+
+
+def test_no_gpu_means_loud_failure():
+    from yolo_amd.yolov5_official.utils import non_max_suppression
+    with pytest.raises(RuntimeError):
+        non_max_suppression(torch.zeros(1, 8, 85))
+    net = build_fa("v3tiny", 64)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 64))
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "yolo_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read(), f
+
+
+# ---- structure ---------------------------------------------------------------------------------------------------
+def test_state_dict_structure_matches_reference():
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "g8_structure.json")))
+    keys = lambda m: [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    assert keys(build_v5s(80)) == ref["yolov5s_nc80"]
+    for tag, size in (("v3tiny", 416), ("v2d19", 416), ("v3spp", 608), ("v3", 416), ("v4", 608)):
+        assert keys(build_fa(tag, size)) == ref[tag], tag
+
+
+def test_v5s_torch_face_matches_golden(golden):
+    """CPU tensors / training mode run stock torch ops with the reference's module semantics."""
+    from yolo_amd.synthetic import images
+    g = golden("g6_v5s_nc20_64")
+    m = build_v5s(20)
+    with torch.no_grad():
+        z, xs = m(images(2, 64, seed=64))
+    np.testing.assert_allclose(z.numpy(), g["z"], rtol=1e-5, atol=1e-5)
+    m.train()
+    out = m(images(2, 64, seed=64))
+    assert isinstance(out, list) and tuple(out[0].shape) == (2, 3, 8, 8, 25)
+
+
+def test_planner_v5s_on_cpu():
+    """The launch list can be planned without a GPU: op mix, concat by redirection, FLOP bookkeeping."""
+    from yolo_amd import engine
+    m = build_v5s(80)
+    g = engine.Graph("cpu", "bf16")
+    m._lower(g, 2, 3, 640, 640)
+    plan = g.finalize()
+    kinds = [k for k, _ in g.ops]
+    assert kinds.count("conv") == 62 and "copy" not in kinds and kinds.count("spp") == 1 and kinds.count("upsample") == 2
+    gflop = sum(i["flops"] for i in plan.op_info) / 2 / 1e9
+    assert abs(gflop - 16.96) < 0.01          # conv FLOPs per 640x640 image of YOLOv5s
+    heads = [op for op in plan.ops if op.kind == 0 and op.conv.out_dtype == 0]
+    assert len(heads) == 3 and all(h.conv.Cout == 255 and h.conv.cout_store == 256 and h.conv.y_ld == 256 for h in heads)
+
+
+@pytest.mark.parametrize("tag,size,convs", [("v3tiny", 416, 13), ("v2d19", 416, 23), ("v3spp", 608, 75), ("v4", 608, 125)])
+def test_planner_family_a_on_cpu(tag, size, convs):
+    from yolo_amd import engine
+    from yolo_amd.models._anchor_detector import _HeadLowerOps
+    net = build_fa(tag, size)
+    g = engine.Graph("cpu", "fp32")
+    heads = net._heads(_HeadLowerOps(g), g.input_nchw(1, 3, size, size))
+    kinds = [k for k, _ in g.ops]
+    assert kinds.count("conv") == convs and "copy" not in kinds
+    assert len(heads) == len(FA_SPECS[tag][3])
+
+
+# ---- host-side metric code against the golden vectors -------------------------------------------------------------
+def test_v5_metric_helpers(golden):
+    from yolo_amd.yolov5_official import utils as U
+    g = golden("g7_v5_metrics")
+    np.testing.assert_allclose(U.box_iou(torch.from_numpy(g["box1"]), torch.from_numpy(g["box2"])).numpy(), g["iou"], rtol=1e-6)
+    np.testing.assert_array_equal(U.xywh2xyxy(torch.from_numpy(g["xywh"])).numpy(), g["xyxy"])
+    np.testing.assert_allclose(U.xyxy2xywh(torch.from_numpy(g["xyxy"])).numpy(), g["xywh_back"], rtol=1e-6)
+    np.testing.assert_allclose(U.scale_coords((640, 640), torch.from_numpy(g["coords"]).clone(), (480, 360)).numpy(), g["scaled1"], rtol=1e-6)
+    np.testing.assert_allclose(U.scale_coords((384, 640), torch.from_numpy(g["coords"]).clone(), (720, 1280),
+                                              ((0.5, 0.5), (0.0, 12.0))).numpy(), g["scaled2"], rtol=1e-6)
+    correct = U.process_batch(torch.from_numpy(g["preds"]), torch.from_numpy(g["labels"]), torch.from_numpy(g["iouv"]))
+    np.testing.assert_array_equal(correct.numpy(), g["correct"])
+    p, r, ap, f1, cls = U.ap_per_class(g["tp"], g["conf"], g["pcls"], g["tcls"])
+    np.testing.assert_allclose(ap, g["ap"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(p, g["p"], rtol=1e-12)
+    np.testing.assert_allclose(r, g["r"], rtol=1e-12)
+    np.testing.assert_allclose(f1, g["f1"], rtol=1e-12)
+    np.testing.assert_array_equal(cls, g["ap_class"])
+    one = U.compute_ap(g["rec"], g["prec"])
+    np.testing.assert_allclose(one[0], g["ap_one"], rtol=1e-12)
+    np.testing.assert_allclose(one[1], g["mpre"], rtol=1e-12)
+
+
+def _voc_fixture(golden):
+    from yolo_amd.data.vocapi_evaluator import VOCAPIEvaluator
+    g = golden("g7_voc")
+    names = [str(n) for n in g["names"]]
+    labelmap = [str(c) for c in g["labelmap"]]
+    gts = json.loads(str(g["gts"]))
+    ds = type("DS", (), {"ids": [("", n) for n in names], "__len__": lambda self: len(names)})()
+    ev = VOCAPIEvaluator("/nonexistent/", 416, None, labelmap, dataset=ds, annotations=gts)
+    boxes = [[g[f"boxes_{ci}_{ii}"] for ii in range(len(names))] for ci in range(len(labelmap))]
+    return g, ev, boxes
+
+
+def test_voc_metric(golden):
+    from yolo_amd.data.vocapi_evaluator import voc_ap
+    g, ev, boxes = _voc_fixture(golden)
+    pr = golden("g7_v5_metrics")
+    assert abs(voc_ap(pr["rec"], pr["prec"], True) - float(g["voc_ap07"])) < 1e-12
+    assert abs(voc_ap(pr["rec"], pr["prec"], False) - float(g["voc_ap_area"])) < 1e-12
+    assert abs(ev.evaluate_detections(boxes) - float(g["map"])) < 1e-12
+    np.testing.assert_allclose(ev.aps, g["aps"], rtol=0, atol=1e-12)
+    assert ev.aps[3] == -1.0
+    ev.evaluate_detections(boxes, use_07=False)
+    np.testing.assert_allclose(ev.aps, g["aps_area"], rtol=0, atol=1e-12)
+
+
+# ---- data-parallel exchange: 2 ranks over gloo ---------------------------------------------------------------------
+WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from yolo_amd import distributed as yd
+rank, world, _ = yd.init_from_env("cpu")
+assert world == 2 and yd.world() == (rank, 2)
+# shard_range partitions without gaps
+n = 37
+lo, hi = yd.shard_range(n, rank, world)
+parts = [None, None]; dist.all_gather_object(parts, (lo, hi))
+assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == n
+# ragged all-gather of per-image detections
+g = torch.Generator().manual_seed(5)
+det_all = torch.rand(n, 300, 6, generator=g); cnt_all = torch.randint(0, 300, (n,), generator=g, dtype=torch.int32)
+ids = torch.arange(lo, hi)
+det, cnt, iid = yd.all_gather_detections(det_all[lo:hi], cnt_all[lo:hi], ids)
+assert torch.equal(det, det_all) and torch.equal(cnt, cnt_all) and torch.equal(iid, torch.arange(n))
+# empty shard on one rank
+d2 = yd.all_gather_rows(det_all[:5] if rank == 0 else det_all[:0])
+assert torch.equal(d2, det_all[:5])
+# VOC evaluator: evaluate() shards the image list, detects rank-locally, all-gathers, AP identical to one process
+from conftest import load_golden
+from test_host import _voc_fixture
+gold, ev, boxes = _voc_fixture(load_golden)
+class DS:
+    ids = ev.dataset.ids
+    def __len__(self): return len(self.ids)
+    def pull_item(self, i): return torch.full((3, 4, 4), float(i)), None, 1, 1
+ev.dataset = DS()
+class FakeNet:
+    seen = []
+    def eval(self): return self
+    def detect_batch(self, x):
+        idx = [int(v) for v in x[:, 0, 0, 0].tolist()]
+        FakeNet.seen += idx
+        rows = []
+        for i in idx:
+            r = [np.concatenate([boxes[ci][i], np.full((len(boxes[ci][i]), 1), ci, np.float32)], 1)
+                 for ci in range(len(ev.labelmap)) if len(boxes[ci][i])]
+            rows.append(np.concatenate(r, 0) if r else np.zeros((0, 6), np.float32))
+        k = max(max(len(r) for r in rows), 1)
+        d = torch.zeros(len(idx), k, 6); keep = torch.zeros(len(idx), k, dtype=torch.int32)
+        for j, r in enumerate(rows):
+            d[j, :len(r)] = torch.from_numpy(r); keep[j, :len(r)] = 1
+        return d[..., :4], keep, d[..., 5].long(), d[..., 4]
+mAP = ev.evaluate(FakeNet(), batch_size=2, device="cpu")
+lo, hi = yd.shard_range(len(DS.ids), rank, world)
+assert FakeNet.seen == list(range(lo, hi)), (FakeNet.seen, lo, hi)      # each rank detected only its shard
+assert abs(mAP - float(gold["map"])) < 1e-12
+np.testing.assert_allclose(ev.aps, gold["aps"], rtol=0, atol=1e-12)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_exchange(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

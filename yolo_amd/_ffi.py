@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("res_ld", C.c_int32), ("res_coff", C.c_int32),
         ("kp", C.c_int32), ("cout_pad", C.c_int32),
         ("act", C.c_int32), ("slope", C.c_float), ("res_mode", C.c_int32),
-        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("cout_store", C.c_int32),
     ]
 
 

@@ -18,8 +18,16 @@
 // group (rows l&15, chunk l>>4) touch 16 distinct 16-byte bank slots, so fragment reads are
 // conflict-free on 64-byte rows.
 //
-// Pipeline: global -> registers -> LDS, two LDS stages, one barrier per K-step; the global loads of
-// step k+1 are issued before the MFMAs of step k and written to the other stage after them.
+// Two kernels share that image:
+//   conv_dma_kernel     Cin a multiple of the K-step (every layer but the first): a K-step never straddles a
+//                       filter tap, so the tap is workgroup-uniform (scalar) and each staged row is one
+//                       precomputed pointer + a per-tap validity bit.  Tiles go global -> LDS directly
+//                       (LDS-DMA, global_load_lds_dwordx4; padded taps read a zero page) through a 3-stage
+//                       ring with two tiles in flight behind a counted vmcnt and one raw barrier per K-step.
+//                       The output tile leaves through LDS so that every store is a full 16-byte piece of a
+//                       contiguous channel run.
+//   conv_generic_kernel any Cin that is a multiple of the chunk: per-thread tap tracking, global ->
+//                       registers -> LDS, two stages.
 #include "ydet_internal.h"
 
 using namespace ydet;
@@ -39,6 +47,8 @@ struct ConvArgs {
     long long M;      // N*Ho*Wo
     int tiles_n;      // channel tiles
     int vec_store;    // 4-channel vector stores are legal
+    int cout_store;   // channels written per pixel (>= Cout; the extra ones are zero-weight rows)
+    int lds_epilogue; // 16-byte coalesced stores through LDS are legal
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -102,7 +112,7 @@ __device__ __forceinline__ void store4<__bf16>(char* p, const float (&v)[4]) {
 
 // BN x BM output tile (channels x pixels) per 256-thread workgroup, WARPS_N x WARPS_M waves.
 template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool IS1X1>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) void conv_generic_kernel(const ConvArgs a) {
     static_assert(WARPS_N * WARPS_M == 4, "four waves per workgroup");
     constexpr int EPC = 16 / (int)sizeof(TIN);  // elements per 16-byte chunk
     constexpr int BK = 4 * EPC;                 // K elements per step (64 bytes)
@@ -280,6 +290,227 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
+
+// 16 zero bytes every padded tap is loaded from (LDS-DMA cannot predicate a lane to zero).
+__device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
+__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
+    static_assert(WARPS_N * WARPS_M == 4, "four waves per workgroup");
+    constexpr int EPC = 16 / (int)sizeof(TIN);
+    constexpr int BK = 4 * EPC;
+    constexpr int WN = BN / WARPS_N, WM = BM / WARPS_M;
+    constexpr int FN = WN / 16, FM = WM / 16;
+    constexpr int WROWS = BN < 64 ? 64 : BN;      // weight rows staged (>= 64 so every wave stages whole groups)
+    constexpr int WJ = WROWS / 64, XJ = BM / 64;  // 16-row groups per wave: weights, pixels
+    constexpr int LPT = WJ + XJ;                  // LDS-DMA instructions per wave and tile
+    constexpr int STAGE = (WROWS + BM) * 64;
+    constexpr int NSTAGE = 3;
+    constexpr int ROWB = BN * (int)sizeof(TOUT) + 16;  // epilogue row pitch (pad: spreads the 8-byte writes over banks)
+    constexpr int NPASS = (BM * ROWB + NSTAGE * STAGE - 1) / (NSTAGE * STAGE);
+    constexpr int PM = BM / NPASS;                     // pixels per epilogue pass
+    static_assert(BM % NPASS == 0 && (PM % WM == 0 || WM % PM == 0), "epilogue pass split");
+    using frag_t = typename Frag<TIN>::type;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WARPS_N, wm = wave / WARPS_N;
+
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const long long tile_m = bid / a.tiles_n;
+    const int n0 = tile_n * BN;
+    const long long m0 = tile_m * BM;
+
+    // ---- staging roles ------------------------------------------------------------------------------
+    // wave-instruction j of a wave fills LDS rows (j*4 + wave)*16 .. +15 of the weight (j < WJ) or pixel
+    // image; lane l lands at physical chunk l&3 of row l>>2 and therefore fetches logical chunk
+    // (l&3) ^ F[(l>>4)&3] (the swizzle lives on the source address, the LDS image stays lane-linear).
+    const int srow = lane >> 2;
+    const int lchunk = (lane & 3) ^ chunk_swz(lane >> 4);
+    const char* wsrc[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+        wsrc[j] = a.w + ((size_t)(n0 + (j * 4 + wave) * 16 + srow) * a.kp + lchunk * EPC) * sizeof(TIN);
+
+    const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    const char* xsrc[XJ];
+    unsigned xmask[XJ];
+    const int HoWo = a.Ho * a.Wo;
+    const int taps = a.KH * a.KW;
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const long long m = m0 + (j * 4 + wave) * 16 + srow;
+        const bool okm = m < a.M;
+        const long long mm = okm ? m : 0;
+        if (pointwise) {
+            xsrc[j] = a.x + ((size_t)mm * a.x_ld + a.x_coff + lchunk * EPC) * sizeof(TIN);
+            xmask[j] = okm ? 1u : 0u;
+        } else {
+            const int n = (int)(mm / HoWo);
+            const int rem = (int)(mm - (long long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+            unsigned mk = 0;
+            if (okm) {
+                for (int t = 0; t < taps; ++t) {
+                    const int kh = t / a.KW, kw = t - kh * a.KW;
+                    if ((unsigned)(hi0 + kh) < (unsigned)a.H && (unsigned)(wi0 + kw) < (unsigned)a.W) mk |= 1u << t;
+                }
+            }
+            xmask[j] = mk;
+            const long long pix = ((long long)n * a.H + hi0) * a.W + wi0;  // may be "before" the image: masked
+            xsrc[j] = a.x + (pix * a.x_ld + a.x_coff + lchunk * EPC) * (long long)sizeof(TIN);
+        }
+    }
+    const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
+
+    // workgroup-uniform walk over K: tap index and channel offset of the current K-step
+    int tap = 0, c0 = 0, kh = 0, kw = 0;
+    long long tapoff = 0;  // byte offset of (kh, kw, c0) relative to a row pointer
+    int ktile = 0;         // next tile to issue
+
+    auto issue = [&](int stage) {
+        char* dst = smem + stage * STAGE + wave * 1024;
+        const long long woff = (long long)ktile * BK * (long long)sizeof(TIN);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + woff),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const bool ok = (xmask[j] >> tap) & 1u;
+            const char* src = ok ? xsrc[j] + tapoff : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + WROWS * 64 + j * 4096), 16,
+                                             0, 0);
+        }
+        ++ktile;
+        c0 += BK;
+        if (c0 == a.Cin) {
+            c0 = 0;
+            ++tap;
+            if (++kw == a.KW) { kw = 0; ++kh; }
+        }
+        tapoff = ((long long)(kh * a.W + kw) * a.x_ld + c0) * (long long)sizeof(TIN);
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr_off = (lane & 15) * 64 + (((lane >> 4) ^ chunk_swz(lane >> 2)) << 4);
+
+    const int nk = a.kp / BK;
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most one younger tile (LPT instructions) is still in flight
+        if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // every wave is past its reads of stage (kt-1)%3 == (kt+2)%3: refill it
+        if (kt + 2 < nk) issue((kt + 2) % NSTAGE);
+        const char* ws = smem + (kt % NSTAGE) * STAGE + (wn * WN) * 64 + fr_off;
+        const char* xs = smem + (kt % NSTAGE) * STAGE + WROWS * 64 + (wm * WM) * 64 + fr_off;
+        frag_t fa[FN], fb[FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) fa[i] = *reinterpret_cast<const frag_t*>(ws + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) fb[j] = *reinterpret_cast<const frag_t*>(xs + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------------
+    const int q = lane >> 4, px = lane & 15;
+    if (a.lds_epilogue) {
+        constexpr int V = 16 / (int)sizeof(TOUT);       // channels per 16-byte piece
+        constexpr int PIECES = BN / V;                  // pieces per pixel row of the tile
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            __builtin_amdgcn_s_barrier();               // the ring / the previous pass is no longer read
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int pl = wm * WM + j * 16 + px;   // pixel inside the tile
+                if (pl / PM != pass) continue;
+                const long long m = m0 + pl;
+                const char* rrow = (a.res && m < a.M) ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
+                char* lrow = smem + (pl - pass * PM) * ROWB;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const int cl = wn * WN + i * 16 + q * 4;   // channel inside the tile
+                    const int co = n0 + cl;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (a.bias) {
+                        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    float r[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
+                    if (a.res_mode == YDET_RES_BEFORE_ACT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = activate(v[e] + r[e], a.act, a.slope);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = activate(v[e], a.act, a.slope) + r[e];
+                    }
+                    store4<TOUT>(lrow + cl * sizeof(TOUT), v);
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < PM * PIECES; idx += 256) {
+                const int pl = idx / PIECES, piece = idx - pl * PIECES;
+                const long long m = m0 + pass * PM + pl;
+                const int co = n0 + piece * V;
+                if (m < a.M && co < a.cout_store) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + pl * ROWB + piece * 16);
+                    *reinterpret_cast<u32x4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT)) = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const long long m = m0 + wm * WM + j * 16 + px;
+        if (m >= a.M) continue;
+        char* yrow = a.y + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
+        const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int co = n0 + wn * WN + i * 16 + q * 4;
+            if (co >= a.Cout) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (co + e >= a.Cout) break;
+                float r = 0.f;
+                if (rrow) r = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
+                float o = a.res_mode == YDET_RES_BEFORE_ACT ? activate(v[e] + r, a.act, a.slope)
+                                                            : activate(v[e], a.act, a.slope) + r;
+                reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(o);
+            }
+        }
+    }
+}
+
 template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
 int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
@@ -287,15 +518,30 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     const long long tiles_m = (a.M + BM - 1) / BM;
     const long long nblk = tiles_m * a.tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(YDET_ERR_ARG, "conv: grid of %lld blocks", nblk);
+    constexpr int BK = 64 / (int)sizeof(TIN);
+    // uniform-tap LDS-DMA kernel; the 32-channel tile keeps the register-staged kernel (measured faster there:
+    // its weight image is half padding under the DMA group layout)
+    if (BN >= 64 && a.Cin % BK == 0 && a.KH * a.KW <= 32) {
+        constexpr int WROWS = BN < 64 ? 64 : BN;
+        const size_t lds_dma = 3 * (size_t)(WROWS + BM) * 64;
+        a.lds_epilogue = (a.y_ld % (16 / (int)sizeof(TOUT)) == 0 && a.y_coff % (16 / (int)sizeof(TOUT)) == 0 &&
+                          a.cout_store % (16 / (int)sizeof(TOUT)) == 0)
+                             ? 1
+                             : 0;
+        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M>), dim3((unsigned)nblk), dim3(256),
+                           lds_dma, stream, a);
+        YDET_CHECK_LAUNCH("conv_dma_kernel");
+        return YDET_OK;
+    }
     const size_t lds = 2 * (size_t)(BN + BM) * 64;
     const bool is1x1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
     if (is1x1)
-        hipLaunchKernelGGL((conv_igemm_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, true>), dim3((unsigned)nblk),
+        hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, true>), dim3((unsigned)nblk),
                            dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
+        hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
                            dim3(256), lds, stream, a);
-    YDET_CHECK_LAUNCH("conv_igemm_kernel");
+    YDET_CHECK_LAUNCH("conv_generic_kernel");
     return YDET_OK;
 }
 
@@ -325,6 +571,9 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
                    "conv: Cin/x_ld/x_coff (%d,%d,%d) must be multiples of %d", d->Cin, d->x_ld, d->x_coff, epc);
     YDET_CHECK_ARG(d->x_coff >= 0 && d->x_coff + d->Cin <= d->x_ld, "conv: input slice exceeds x_ld");
     YDET_CHECK_ARG(d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld, "conv: output slice exceeds y_ld");
+    YDET_CHECK_ARG(d->cout_store == 0 || (d->cout_store >= d->Cout && d->cout_store <= d->cout_pad &&
+                                          d->y_coff + d->cout_store <= d->y_ld),
+                   "conv: cout_store %d (need Cout <= cout_store <= cout_pad and inside y_ld)", d->cout_store);
     YDET_CHECK_ARG(d->kp % bk == 0 && d->kp >= d->KH * d->KW * d->Cin, "conv: kp %d (need multiple of %d, >= %d)",
                    d->kp, bk, d->KH * d->KW * d->Cin);
     YDET_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->Cout, "conv: cout_pad %d", d->cout_pad);
@@ -346,6 +595,8 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
     a.kp = d->kp; a.act = d->act; a.res_mode = d->res_mode; a.slope = d->slope;
     a.M = (long long)d->N * d->Ho * d->Wo;
     a.tiles_n = 0;
+    a.lds_epilogue = 0;
+    a.cout_store = d->cout_store > 0 ? d->cout_store : d->Cout;
     a.vec_store = (d->Cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0 &&
                    (!d->res || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0)))
                       ? 1

@@ -131,6 +131,61 @@ __global__ void spp_kernel(const SliceArgs a) {
     vstore<T, V>(y0 + 2 * a.C, o);
 }
 
+// SPP for small maps (H*W <= kSppMaxHW, every SPP in the reference models runs on 19x19 .. 20x20): one
+// workgroup owns one image x 4 channel vectors, keeps the plane in LDS and builds the three pools as a
+// cascade of separable 5-wide max filters (5x5, then 5x5 of that = 9x9, then again = 13x13: exact for max,
+// and implicit -inf padding is preserved because out-of-range taps are simply skipped at every stage).
+constexpr int kSppMaxHW = 512;
+constexpr int kSppGV = 4;   // channel vectors (16 bytes each) per workgroup
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void spp_lds_kernel(const SliceArgs a) {
+    __shared__ __attribute__((aligned(16))) T buf[2][kSppMaxHW * kSppGV * V];
+    const int hw = a.H * a.W;
+    const int groups = a.cv / kSppGV;           // host guarantees cv % kSppGV == 0
+    const int n = blockIdx.x / groups;
+    const int c = (blockIdx.x - n * groups) * kSppGV * V;
+    const T* xin = reinterpret_cast<const T*>(a.x) + (size_t)n * hw * a.x_ld + a.x_coff + c;
+    T* yout = reinterpret_cast<T*>(a.y) + (size_t)n * hw * a.y_ld + a.y_coff + c;
+    const int items = hw * kSppGV;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int p = it / kSppGV, v = it - p * kSppGV;
+        vstore<T, V>(&buf[0][it * V], vload<T, V>(xin + (size_t)p * a.x_ld + v * V));
+    }
+    __syncthreads();
+    for (int stage = 0; stage < 3; ++stage) {
+        // row pass: buf[0] -> buf[1]
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int p = it / kSppGV, v = it - p * kSppGV;
+            const int h = p / a.W, w = p - h * a.W;
+            Vec<T, V> m = vload<T, V>(&buf[0][it * V]);
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                if (d == 0) continue;
+                const int ww = w + d;
+                if ((unsigned)ww < (unsigned)a.W) vmax(m, vload<T, V>(&buf[0][((h * a.W + ww) * kSppGV + v) * V]));
+            }
+            vstore<T, V>(&buf[1][it * V], m);
+        }
+        __syncthreads();
+        // column pass: buf[1] -> buf[0] and the output slice of this stage
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int p = it / kSppGV, v = it - p * kSppGV;
+            const int h = p / a.W, w = p - h * a.W;
+            Vec<T, V> m = vload<T, V>(&buf[1][it * V]);
+#pragma unroll
+            for (int d = -2; d <= 2; ++d) {
+                if (d == 0) continue;
+                const int hh = h + d;
+                if ((unsigned)hh < (unsigned)a.H) vmax(m, vload<T, V>(&buf[1][((hh * a.W + w) * kSppGV + v) * V]));
+            }
+            vstore<T, V>(&buf[0][it * V], m);
+            vstore<T, V>(yout + (size_t)p * a.y_ld + stage * a.C + v * V, m);
+        }
+        __syncthreads();
+    }
+}
+
 // Upsample x2: mode 0 nearest, mode 1 bilinear with align_corners=True (fp32 interpolation, the
 // operation order of ATen's upsample_bilinear2d: w0h*(w0w*v00 + w1w*v01) + w1h*(w0w*v10 + w1w*v11)).
 template <typename T, int V>
@@ -221,6 +276,15 @@ int run_slice(int kind, const ydet_slice_desc* d, int mode, hipStream_t stream) 
     a.total = (long long)d->N * Ho * Wo * a.cv;
     const long long grid = (a.total + 255) / 256;
     YDET_CHECK_ARG(grid > 0 && grid < 0x7fffffffLL, "slice op: grid");
+    if (kind == K_SPP && vec && d->H * d->W <= kSppMaxHW && a.cv % kSppGV == 0) {
+        const unsigned g = (unsigned)(d->N * (a.cv / kSppGV));
+        if (d->dtype == YDET_BF16)
+            hipLaunchKernelGGL((spp_lds_kernel<__bf16, 8>), dim3(g), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((spp_lds_kernel<float, 4>), dim3(g), dim3(256), 0, stream, a);
+        YDET_CHECK_LAUNCH("spp_lds_kernel");
+        return YDET_OK;
+    }
     if (d->dtype == YDET_BF16) {
         if (vec) launch_kind<__bf16, 8>(kind, a, (unsigned)grid, stream);
         else launch_kind<__bf16, 1>(kind, a, (unsigned)grid, stream);

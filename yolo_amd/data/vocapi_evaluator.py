@@ -19,18 +19,18 @@ from .. import distributed as ydist
 
 def voc_ap(rec, prec, use_07_metric=True):
     """AP from recall / precision arrays (reference :194-225)."""
-    rec, prec = np.asarray(rec, dtype=float), np.asarray(prec, dtype=float)
+    rec, prec = np.asarray(rec), np.asarray(prec)   # the input dtype is kept: a float32 curve accumulates in float32
     if use_07_metric:
         ap = 0.0
         for t in np.arange(0.0, 1.1, 0.1):
             above = rec >= t
-            ap += (prec[above].max() if above.any() else 0.0) / 11.0
+            ap = ap + (prec[above].max() if above.any() else 0.0) / 11.0
         return ap
     mrec = np.concatenate(([0.0], rec, [1.0]))
     mpre = np.concatenate(([0.0], prec, [0.0]))
     mpre = np.maximum.accumulate(mpre[::-1])[::-1]
     step = np.where(mrec[1:] != mrec[:-1])[0]
-    return float(np.sum((mrec[step + 1] - mrec[step]) * mpre[step + 1]))
+    return np.sum((mrec[step + 1] - mrec[step]) * mpre[step + 1])
 
 
 def round_like_results_file(dets):

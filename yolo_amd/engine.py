@@ -294,6 +294,11 @@ class Plan:
         d.kp, d.cout_pad = pc.kp, pc.cout_pad
         d.act, d.slope, d.res_mode = a["act"], a["slope"], a["res_mode"]
         d.in_dtype, d.out_dtype = rx.dtype, ry.dtype
+        # a stand-alone output buffer whose channel count is not a vector multiple (75 / 125 / 255-channel heads)
+        # is stored with its zero pad channels, so that every store is a whole 16-byte piece
+        vec = 4 if ry.dtype == _ffi.F32 else 8
+        if y.st is ry and y.coff == 0 and pc.Cout % vec and _round_up(pc.Cout, vec) <= min(ry.ld, pc.cout_pad):
+            d.cout_store = _round_up(pc.Cout, vec)
 
     def run(self, *xs, timer=None, first_mark=0):
         """xs: the NCHW CUDA inputs (fp32 or bf16; other dtypes are converted to fp32), in the order
