@@ -40,7 +40,9 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* ydet_last_error(void);
-/* ABI version of the library (bumped when a struct below changes). */
+/* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
+ * was built from. */
+#define YDET_ABI_VERSION 3
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -53,6 +55,7 @@ int ydet_abi_version(void);
  *
  * y = act(conv(x, w) + bias) [+ res]            res_mode = AFTER_ACT   (x + act(bn(conv)))
  * y = act(conv(x, w) + bias + res)              res_mode = BEFORE_ACT  (act(x + bn(conv)))
+ * then, if post_scale is given,  y = post_act(post_scale * y + post_shift).
  *
  * Weights are pre-packed by the caller as w[cout_pad][kp], row-major, in `in_dtype`, with
  * k = (kh*KW + kw)*Cin + c, rows >= Cout and columns >= KH*KW*Cin zero.  BatchNorm is folded into
@@ -81,6 +84,14 @@ typedef struct {
     int32_t cout_store; /* 0, or the number of channels written per pixel, Cout <= cout_store <= cout_pad:
                            the extra channels are the zero rows of w (value act(0) = 0); lets a head with
                            255 channels be stored as 256 with whole 16-byte pieces */
+    /* Optional second stage, y = post_act(post_scale[c] * y + post_shift[c]) applied to the finished value:
+     * the BatchNorm + LeakyReLU that follows a torch.cat whose producer already ended in BN + activation
+     * (utils/moduleUtils.py:209-214 `tie`, models/v5v2.py:86-97 `last`).  Both arrays have cout_pad fp32
+     * entries; both NULL = no second stage. */
+    const float* post_scale;
+    const float* post_shift;
+    int32_t post_act;  /* ydet_act */
+    float post_slope;
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 

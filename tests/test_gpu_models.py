@@ -76,6 +76,71 @@ def test_block_golden(golden, compute, tag):
         assert not any(k == "copy" for k, _ in gr.ops)
 
 
+# ---- own-v5 blocks and models: post-concat BatchNorm + LeakyReLU, weight-shared repeats, raw head maps ----------------
+def _own_block(tag):
+    from yolo_amd.models import v5v2 as V
+    from yolo_amd.utils import moduleUtils as A
+    table = {
+        "g9_a_cspresunit": lambda: A.CSPResUnit(32, 32, 2), "g9_a_cspmodule": lambda: A.CSPModule(64, 64, n=3, e=[0.33, 0.5]),
+        "g9_a_focus": lambda: A.Focus(3, 32, e=0.5), "g9_b_convblock": lambda: V.ConvBlock(16, 32, 3, 2),
+        "g9_b_cspresunit": lambda: V.CSPResUnit(32, 32, 3), "g9_b_cspmodule1": lambda: V.CSPModule1(64, 64, n=3, e=[0.33, 0.5]),
+        "g9_b_cspmodule2": lambda: V.CSPModule2(64, 64, e=0.5, n=2), "g9_b_sppmodule": lambda: V.SPPModule(64, 64, e=0.5),
+        "g9_b_focus": lambda: V.Focus(3, 32, e=0.5),
+    }
+    blk = table[tag]()
+    init_deterministic(blk, seed=5)
+    return blk.eval()
+
+
+OWN_BLOCKS = ["g9_a_cspresunit", "g9_a_cspmodule", "g9_a_focus", "g9_b_convblock", "g9_b_cspresunit", "g9_b_cspmodule1",
+              "g9_b_cspmodule2", "g9_b_sppmodule", "g9_b_focus"]
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", OWN_BLOCKS)
+def test_own_v5_block_golden(golden, compute, tag):
+    g = golden(tag)
+    blk = _own_block(tag).to(DEV)
+    x = torch.from_numpy(g["x"])
+    gr = engine.Graph(DEV, compute)
+    y = engine.lower_any(gr, blk, gr.input_nchw(*x.shape, focus=tag.endswith("focus")))
+    gr.to_nchw(y, "y")
+    out = gr.finalize().run(x.to(DEV))["y"].float().cpu().numpy()
+    assert out.shape == g["y"].shape
+    assert rel_err(out, g["y"]) < TOL[compute], tag
+    assert not any(k == "copy" for k, _ in gr.ops)
+    if tag in ("g9_a_cspresunit", "g9_b_cspresunit"):   # one set of weights, applied repeatedly
+        n = len(blk.main)
+        assert [k for k, _ in gr.ops].count("conv") == 2 * n and n > 1
+        assert len(list(blk.parameters())) == (8 if "_a_" in tag else 6)   # ... of ONE pair
+
+
+def build_own_v5(tag):
+    if tag == "v5":
+        from yolo_amd.models.v5 import YOLOv5
+        net = YOLOv5(nc=20)
+    else:
+        from yolo_amd.models.v5v2 import YOLOv5
+        anchors9 = [[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]]
+        net = YOLOv5(nc=20, anchors=anchors9, input_size=128)
+    init_deterministic(net, seed=0)
+    return net.eval()
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["v5", "v5v2"])
+def test_own_v5_models_golden(golden, compute, tag):
+    g = golden(f"g9_{tag}_128")
+    engine.set_compute_dtype(compute)
+    net = build_own_v5(tag).to(DEV)
+    x = images(2, 128, seed=129, kind="randn").to(DEV)
+    outs = net(x)
+    tol = TOL[compute] if compute == "fp32" else 5e-2
+    for o, name in zip(outs, ("ys", "ym", "yl")):
+        assert tuple(o.shape) == g[name].shape and o.dtype == torch.float32
+        assert rel_err(o.cpu().numpy(), g[name]) < tol, name
+
+
 # ---- YOLOv5s ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("compute", ["fp32", "bf16"])
 @pytest.mark.parametrize("nc", [80, 20])

@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.lib()   # dlopen + dlsym of every symbol; raises if one is missing
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ydet_abi_version() == 2
+    header_version = int(re.search(r"#define YDET_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.ydet_abi_version() == header_version == _ffi.ABI_VERSION
     assert lib.ydet_last_error() == b""
 
 
@@ -72,6 +73,47 @@ def test_state_dict_structure_matches_reference():
     assert keys(build_v5s(80)) == ref["yolov5s_nc80"]
     for tag, size in (("v3tiny", 416), ("v2d19", 416), ("v3spp", 608), ("v3", 416), ("v4", 608)):
         assert keys(build_fa(tag, size)) == ref[tag], tag
+
+
+def test_own_v5_structure_and_torch_face(golden):
+    """models/v5.py and models/v5v2.py mirrors: state_dict keys/shapes and the stock-torch forward."""
+    from yolo_amd.synthetic import images, init_deterministic
+    from yolo_amd.models.v5 import YOLOv5 as V5
+    from yolo_amd.models.v5v2 import YOLOv5 as V5v2
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "g9_structure.json")))
+    anchors9 = [[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]]
+    for tag, net in (("v5", V5(nc=20)), ("v5v2", V5v2(nc=20, anchors=anchors9, input_size=128))):
+        assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == ref[tag], tag
+        init_deterministic(net, seed=0)
+        net.eval()
+        g = golden(f"g9_{tag}_128")
+        with torch.no_grad():
+            outs = net(images(2, 128, seed=129, kind="randn"))
+        for o, name in zip(outs, ("ys", "ym", "yl")):
+            np.testing.assert_allclose(o.numpy(), g[name], rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):    # the reference's default anchor list cannot be reshaped either
+        V5v2(nc=20)
+
+
+def test_planner_own_v5_on_cpu():
+    from yolo_amd import engine
+    from yolo_amd.models._anchor_detector import _HeadLowerOps
+    from yolo_amd.models.v5 import YOLOv5 as V5
+    net = V5(nc=20).eval()
+    g = engine.Graph("cpu", "bf16")
+    heads = net._heads(_HeadLowerOps(g), g.input_nchw(1, 3, 128, 128, focus=True))
+    kinds = [k for k, _ in g.ops]
+    assert "copy" not in kinds and kinds.count("spp") == 1 and kinds.count("upsample") == 2
+    assert sum(1 for k, a in g.ops if k == "conv" and a["post"] is not None) == 8   # one per CSPModule
+    assert [h.C for h in heads] == [75, 75, 75]
+    from yolo_amd.models.v5v2 import YOLOv5 as V5v2
+    anchors9 = [[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]]
+    net = V5v2(nc=20, anchors=anchors9, input_size=128).eval()
+    g = engine.Graph("cpu", "fp32")
+    heads = net._heads(_HeadLowerOps(g), g.input_nchw(1, 3, 128, 128, focus=True))
+    kinds = [k for k, _ in g.ops]
+    assert "copy" not in kinds and kinds.count("spp") == 1 and [h.C for h in heads] == [75, 75, 75]
+    assert sum(1 for k, a in g.ops if k == "conv" and a["post"] is not None) == 3       # the three CSPModule1
 
 
 def test_v5s_torch_face_matches_golden(golden):
@@ -215,7 +257,7 @@ assert FakeNet.seen == list(range(lo, hi)), (FakeNet.seen, lo, hi)      # each r
 assert abs(mAP - float(gold["map"])) < 1e-12
 np.testing.assert_allclose(ev.aps, gold["aps"], rtol=0, atol=1e-12)
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(sys.argv[2], f"ok{rank}"), "w").write("ok")
 '''
 
 
@@ -224,7 +266,7 @@ def test_two_rank_gloo_exchange(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT, str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()

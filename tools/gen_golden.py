@@ -44,6 +44,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default="", help="write only the fixtures whose name starts with this prefix")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     import_reference(args.ref)
@@ -55,6 +56,8 @@ def main():
     from yolo_amd.synthetic import _gen, clustered_predictions, images, init_deterministic
 
     def save(name, **arrs):
+        if not name.startswith(args.only):
+            return
         path = os.path.join(args.out, name + ".npz")
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
         print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
@@ -244,7 +247,7 @@ def main():
         block.eval()
         with torch.no_grad():
             y = block(x)
-        save(f"g5_{tag}", x=x.numpy(), y=y.numpy())
+        save(tag if tag.startswith("g9_") else f"g5_{tag}", x=x.numpy(), y=y.numpy())
 
     x16 = rnd("g5x16", 2, 16, 12, 10)
     x32 = rnd("g5x32", 2, 32, 12, 10)
@@ -405,8 +408,37 @@ def main():
     struct["v3"] = keys_of(fa_model("models.v3", "YOLOv3", 416, rcfg.yolov3_d53_cfg))
     struct["v4"] = keys_of(fa_model("models.v4", "YOLOv4", 608, rcfg.yolov4_cfg))
     struct["notes"] = notes
-    with open(os.path.join(args.out, "g8_structure.json"), "w") as fh:
-        json.dump(struct, fh)
+    if "g8_structure".startswith(args.only):
+        with open(os.path.join(args.out, "g8_structure.json"), "w") as fh:
+            json.dump(struct, fh)
+
+    # ================= G9: the author's own YOLOv5 re-creations (models/v5.py, models/v5v2.py) =========
+    # blocks with a post-concat BatchNorm + LeakyReLU and with weight-shared repeated sub-blocks
+    import models.v5 as rv5
+    import models.v5v2 as rv5v2
+    block_case("g9_a_cspresunit", fa_mods.CSPResUnit(32, 32, 2), x32)
+    block_case("g9_a_cspmodule", fa_mods.CSPModule(64, 64, n=3, e=[0.33, 0.5]), x32)
+    block_case("g9_a_focus", fa_mods.Focus(3, 32, e=0.5), rnd("g9focus", 2, 3, 16, 12))
+    block_case("g9_b_convblock", rv5v2.ConvBlock(16, 32, 3, 2), x16)
+    block_case("g9_b_cspresunit", rv5v2.CSPResUnit(32, 32, 3), x32)
+    block_case("g9_b_cspmodule1", rv5v2.CSPModule1(64, 64, n=3, e=[0.33, 0.5]), x32)
+    block_case("g9_b_cspmodule2", rv5v2.CSPModule2(64, 64, e=0.5, n=2), x32)
+    block_case("g9_b_sppmodule", rv5v2.SPPModule(64, 64, e=0.5), rnd("g9spp", 2, 32, 20, 20))
+    block_case("g9_b_focus", rv5v2.Focus(3, 32, e=0.5), rnd("g9focus2", 2, 3, 16, 12))
+    anchors9 = [[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]]
+    own = {"v5": rv5.YOLOv5(nc=20), "v5v2": rv5v2.YOLOv5(nc=20, anchors=anchors9, input_size=128)}
+    struct9 = {}
+    for tag, net in own.items():
+        init_deterministic(net, seed=0)
+        net.eval()
+        struct9[tag] = keys_of(net)
+        x = images(2, 128, seed=129, kind="randn")
+        with torch.no_grad():
+            ys, ym, yl = net(x)
+        save(f"g9_{tag}_128", x_seed=129, ys=ys.numpy(), ym=ym.numpy(), yl=yl.numpy())
+    if "g9_structure".startswith(args.only):
+        with open(os.path.join(args.out, "g9_structure.json"), "w") as fh:
+            json.dump(struct9, fh)
     print("notes:", notes)
 
 

@@ -15,6 +15,7 @@ RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
  OP_NHWC2NCHW) = range(9)
 MAX_ANCHORS = 8
+ABI_VERSION = 3   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -29,6 +30,7 @@ class ConvDesc(C.Structure):
         ("kp", C.c_int32), ("cout_pad", C.c_int32),
         ("act", C.c_int32), ("slope", C.c_float), ("res_mode", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("cout_store", C.c_int32),
+        ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("post_act", C.c_int32), ("post_slope", C.c_float),
     ]
 
 
@@ -111,6 +113,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if handle.ydet_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {handle.ydet_abi_version()}, this binding needs {ABI_VERSION}: "
+                               "rebuild with `make -C yolo_amd/csrc`")
         _lib = handle
     return _lib
 

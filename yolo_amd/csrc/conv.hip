@@ -49,6 +49,10 @@ struct ConvArgs {
     int vec_store;    // 4-channel vector stores are legal
     int cout_store;   // channels written per pixel (>= Cout; the extra ones are zero-weight rows)
     int lds_epilogue; // 16-byte coalesced stores through LDS are legal
+    const float* post_scale;  // second per-channel affine + activation applied to the finished value, or null
+    const float* post_shift;
+    int post_act;
+    float post_slope;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -83,6 +87,30 @@ __device__ __forceinline__ float activate(float v, int act, float slope) {
     if (act == YDET_ACT_LEAKY) return v > 0.f ? v : v * slope;
     if (act == YDET_ACT_SILU) return v / (1.0f + __expf(-v));
     return v;
+}
+
+// Four consecutive output channels co..co+3 of one pixel: bias, residual (either order), activation, and the
+// optional second affine + activation (a BatchNorm + activation that follows a concatenation).
+__device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], int co, const ConvArgs& a) {
+    if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (a.res_mode == YDET_RES_BEFORE_ACT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = activate(v[e] + r[e], a.act, a.slope);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = activate(v[e], a.act, a.slope) + r[e];
+    }
+    if (a.post_scale) {
+        const float4 ps = *reinterpret_cast<const float4*>(a.post_scale + co);
+        const float4 pb = *reinterpret_cast<const float4*>(a.post_shift + co);
+        v[0] = activate(v[0] * ps.x + pb.x, a.post_act, a.post_slope);
+        v[1] = activate(v[1] * ps.y + pb.y, a.post_act, a.post_slope);
+        v[2] = activate(v[2] * ps.z + pb.z, a.post_act, a.post_slope);
+        v[3] = activate(v[3] * ps.w + pb.w, a.post_act, a.post_slope);
+    }
 }
 
 template <typename T>
@@ -260,31 +288,19 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(const ConvArgs a) {
             const int co = n0 + wn * WN + i * 16 + q * 4;
             if (co >= a.Cout) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
             if (a.vec_store) {
-                float r[4] = {0.f, 0.f, 0.f, 0.f};
                 if (rrow) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
-                if (a.res_mode == YDET_RES_BEFORE_ACT) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = activate(v[e] + r[e], a.act, a.slope);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = activate(v[e], a.act, a.slope) + r[e];
-                }
+                finish4(v, r, co, a);
                 store4<TOUT>(yrow + (size_t)co * sizeof(TOUT), v);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (co + e >= a.Cout) break;
-                    float r = 0.f;
-                    if (rrow) r = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
-                    float o = a.res_mode == YDET_RES_BEFORE_ACT ? activate(v[e] + r, a.act, a.slope)
-                                                                : activate(v[e], a.act, a.slope) + r;
-                    reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(o);
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
+                finish4(v, r, co, a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
             }
         }
     }
@@ -454,19 +470,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
                     const int cl = wn * WN + i * 16 + q * 4;   // channel inside the tile
                     const int co = n0 + cl;
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    if (a.bias) {
-                        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    }
                     float r[4] = {0.f, 0.f, 0.f, 0.f};
                     if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
-                    if (a.res_mode == YDET_RES_BEFORE_ACT) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = activate(v[e] + r[e], a.act, a.slope);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = activate(v[e], a.act, a.slope) + r[e];
-                    }
+                    finish4(v, r, co, a);
                     store4<TOUT>(lrow + cl * sizeof(TOUT), v);
                 }
             }
@@ -494,19 +500,14 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
             const int co = n0 + wn * WN + i * 16 + q * 4;
             if (co >= a.Cout) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (co + e >= a.Cout) break;
-                float r = 0.f;
-                if (rrow) r = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
-                float o = a.res_mode == YDET_RES_BEFORE_ACT ? activate(v[e] + r, a.act, a.slope)
-                                                            : activate(v[e], a.act, a.slope) + r;
-                reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(o);
-            }
+            for (int e = 0; e < 4; ++e)
+                if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
+            finish4(v, r, co, a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
         }
     }
 }
@@ -579,6 +580,9 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
     YDET_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->Cout, "conv: cout_pad %d", d->cout_pad);
     YDET_CHECK_ARG(d->act >= 0 && d->act <= 2 && d->res_mode >= 0 && d->res_mode <= 2, "conv: bad act/res_mode");
     YDET_CHECK_ARG((d->res != nullptr) == (d->res_mode != YDET_RES_NONE), "conv: res pointer vs res_mode");
+    YDET_CHECK_ARG((d->post_scale != nullptr) == (d->post_shift != nullptr) && d->post_act >= 0 && d->post_act <= 2 &&
+                       ((uintptr_t)d->post_scale & 15) == 0 && ((uintptr_t)d->post_shift & 15) == 0,
+                   "conv: post_scale/post_shift must both be given (16-byte aligned) or both be null");
     YDET_CHECK_ARG(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 15) == 0 &&
                        ((uintptr_t)d->bias & 15) == 0 && ((uintptr_t)d->res & 15) == 0,
                    "conv: pointers must be 16-byte aligned");
@@ -596,6 +600,7 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
     a.M = (long long)d->N * d->Ho * d->Wo;
     a.tiles_n = 0;
     a.lds_epilogue = 0;
+    a.post_scale = d->post_scale; a.post_shift = d->post_shift; a.post_act = d->post_act; a.post_slope = d->post_slope;
     a.cout_store = d->cout_store > 0 ? d->cout_store : d->Cout;
     a.vec_store = (d->Cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0 &&
                    (!d->res || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0)))

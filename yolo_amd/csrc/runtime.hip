@@ -27,7 +27,7 @@ void clear_error() { g_err[0] = 0; }
 }  // namespace ydet
 
 extern "C" const char* ydet_last_error(void) { return ydet::g_err; }
-extern "C" int ydet_abi_version(void) { return 2; }
+extern "C" int ydet_abi_version(void) { return YDET_ABI_VERSION; }
 
 struct ydet_timer {
     int n_marks;

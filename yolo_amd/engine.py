@@ -137,13 +137,29 @@ class Graph:
         t = self.new(N, Ho, Wo, _round_up(c_out, self.vec))
         self.ops.append(("nchw2nhwc", dict(y=t, N=N, C=Cch, H=H, W=W, focus=int(focus), c_pad=t.C, src_dtype=src_dtype)))
         self.ext_in.append(len(self.ops) - 1)
+        t.focused = bool(focus)
         return t
 
     # ---- operators -----------------------------------------------------------------------------
     def conv(self, x, conv, bn=None, bn_slice=None, act=_ffi.ACT_NONE, slope=0.0, res=None,
-             res_mode=_ffi.RES_NONE, out=None, out_dtype=None, external=False):
+             res_mode=_ffi.RES_NONE, out=None, out_dtype=None, external=False, post=None):
+        """post = (bn, channel range or None, act, slope): a second BatchNorm + activation applied to the
+        finished value (the normalisation that follows a concatenation of already-activated branches)."""
         pc = pack_conv(conv, bn, bn_slice, cin_phys=x.C, dtype=self.dt, device=self.device)
         self.keep.append(pc)
+        post_rec = None
+        if post is not None:
+            pbn, psl, pact, pslope = post
+            sl = slice(*psl) if psl is not None else slice(None)
+            f32 = lambda t: t.detach().to(device=self.device, dtype=torch.float32)[sl]
+            scale = f32(pbn.weight) / torch.sqrt(f32(pbn.running_var) + pbn.eps)
+            shift = f32(pbn.bias) - f32(pbn.running_mean) * scale
+            assert scale.numel() == pc.Cout, "post-BatchNorm slice does not match the conv's output channels"
+            ps = torch.zeros(pc.cout_pad, device=self.device)
+            pb = torch.zeros(pc.cout_pad, device=self.device)
+            ps[:pc.Cout], pb[:pc.Cout] = scale, shift
+            self.keep.append((ps, pb))
+            post_rec = (ps, pb, pact, float(pslope))
         s, p = conv.stride[0], conv.padding[0]
         Ho = (x.H + 2 * p - pc.KH) // s + 1
         Wo = (x.W + 2 * p - pc.KW) // s + 1
@@ -153,7 +169,7 @@ class Graph:
         if res is not None:
             assert (res.N, res.H, res.W, res.C) == (out.N, out.H, out.W, out.C), "residual shape mismatch"
         self.ops.append(("conv", dict(x=x, y=out, res=res, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
-                                      res_mode=res_mode if res is not None else _ffi.RES_NONE)))
+                                      res_mode=res_mode if res is not None else _ffi.RES_NONE, post=post_rec)))
         return out
 
     def _slice_op(self, kind, x, out, iarg=0):
@@ -294,6 +310,9 @@ class Plan:
         d.kp, d.cout_pad = pc.kp, pc.cout_pad
         d.act, d.slope, d.res_mode = a["act"], a["slope"], a["res_mode"]
         d.in_dtype, d.out_dtype = rx.dtype, ry.dtype
+        if a.get("post") is not None:
+            ps, pb, pact, pslope = a["post"]
+            d.post_scale, d.post_shift, d.post_act, d.post_slope = ps.data_ptr(), pb.data_ptr(), pact, pslope
         # a stand-alone output buffer whose channel count is not a vector multiple (75 / 125 / 255-channel heads)
         # is stored with its zero pad channels, so that every store is a whole 16-byte piece
         vec = 4 if ry.dtype == _ffi.F32 else 8

@@ -119,8 +119,8 @@ class CSPDarknet(_Backbone):
         return c3, c4, F.run(self.layer5, c4)
 
 
-class CSPDarknetV5(nn.Module):
-    """Backbone of the author's own v5 re-creation (reference :268-294).  Torch-only."""
+class CSPDarknetV5(_Backbone):
+    """Backbone of the author's own v5 re-creation (reference :268-294): Focus stem, CSPModule stages, SPP."""
 
     def __init__(self, e1, e2):
         super().__init__()
@@ -132,7 +132,7 @@ class CSPDarknetV5(nn.Module):
                                    SPP(), Conv(r(1024) // 2 * 4, r(1024), k=1, s=1))
         self.medium = nn.Sequential(Conv(r(256), r(512), k=3, s=2, p=1), CSPModule(512, 512, n=9, e=[e1, e2]))
 
-    def forward(self, x):
-        hb = self.big(x)
-        hm = self.medium(hb)
-        return hb, hm, self.small(hm)
+    def _net(self, F, x):
+        hb = F.run(self.big, x)
+        hm = F.run(self.medium, hb)
+        return hb, hm, F.run(self.small, hm)

@@ -174,8 +174,8 @@ class CSPBottleneck(nn.Module):
 
 
 class CSPResUnit(nn.Module):
-    """The SAME conv-bn-leaky pair applied n times (one set of weights) with an outer shortcut
-    (reference :174-190).  Torch-only: it belongs to the author's own-v5 experiments."""
+    """The SAME conv-bn-leaky pair applied n times (one set of weights, hence one state_dict entry) with an
+    outer shortcut (reference :174-190)."""
 
     def __init__(self, cin, cout, n):
         super().__init__()
@@ -189,10 +189,25 @@ class CSPResUnit(nn.Module):
         y = self.main(x)
         return x + y if self.shortcut else y
 
+    def lower(self, g, x, post=None):
+        if len(self.main) == 0:
+            raise NotImplementedError("CSPResUnit with n = 0")
+        y = x
+        for i, (c1, b1, a1, c2, b2, a2) in enumerate(self.main):
+            last = i == len(self.main) - 1
+            act, slope = activation_code(a1)
+            y = g.conv(y, c1, b1, act=act, slope=slope)
+            act, slope = activation_code(a2)
+            y = g.conv(y, c2, b2, act=act, slope=slope, res=x if last and self.shortcut else None,
+                       res_mode=_ffi.RES_AFTER_ACT, post=post if last else None)
+        return y
+
 
 class CSPModule(nn.Module):
     """tie(cat(up(x), bottom(x))); `res` is constructed (and saved) but not used by forward
-    (reference :193-228).  Torch-only."""
+    (reference :193-228).  On the GPU path the post-concat BatchNorm + LeakyReLU of `tie` is split per half:
+    folded into the plain `bottom` conv, and run as the second epilogue stage of `up` (which already ends in
+    its own BatchNorm + LeakyReLU)."""
 
     def __init__(self, cin, cout, k=1, s=1, p=None, g=1, act=True, n=1, e=None):
         super().__init__()
@@ -213,9 +228,19 @@ class CSPModule(nn.Module):
     def forward(self, x):
         return self.tie(torch.cat([self.up(x), self.bottom(x)], 1))
 
+    def lower(self, g, x):
+        h = self.bottom.out_channels
+        tie_bn, tie_act, tie_conv = self.tie
+        act, slope = activation_code(tie_act)
+        up_act, up_slope = activation_code(self.up[2] if len(self.up) > 2 else None)
+        y1 = g.conv(x, self.up[0], self.up[1], act=up_act, slope=up_slope, post=(tie_bn, (0, h), act, slope))
+        y2 = g.conv(x, self.bottom, tie_bn, (h, 2 * h), act=act, slope=slope)
+        return g.conv(g.cat([y1, y2]), tie_conv)
+
 
 class Focus(nn.Module):
-    """Focus slicing + Conv2d(bias=False) + BN + LeakyReLU(0.01) (reference :231-255).  Torch-only."""
+    """Focus slicing + Conv2d(bias=False) + BN + LeakyReLU(0.01) (reference :231-255).  On the GPU path the
+    slicing happens while the NCHW image is converted to NHWC, so `lower` takes the already sliced tensor."""
 
     def __init__(self, cin, cout, k=3, s=1, p=1, g=1, act=True, e=1.0):
         super().__init__()
@@ -228,3 +253,9 @@ class Focus(nn.Module):
         y = torch.cat([x[..., 0::2, 0::2], x[..., 1::2, 0::2], x[..., 0::2, 1::2], x[..., 1::2, 1::2]], 1)
         y = self.bn(self.conv(y))
         return y if self.act is None else self.act(y)
+
+    def lower(self, g, x):
+        if not getattr(x, "focused", False):
+            raise NotImplementedError("Focus must be the first layer (its slicing is fused into the input conversion)")
+        act, slope = activation_code(self.act)
+        return g.conv(x, self.conv, self.bn, act=act, slope=slope)
