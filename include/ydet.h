@@ -151,9 +151,11 @@ typedef struct {
  * holds the offset (col, row)) and models/yolo.py:42-71 (grid_transposed = 1: its np.meshgrid table makes
  * flat cell f = row*nx + col hold (f / ny, f % ny), which is (row, col) on square maps).
  *   s = sigmoid(raw); xy = (2 s - 0.5 + grid) * stride; wh = (2 s)^2 * anchor; rest = s
- * out is [N, sum_l na*ny*nx, no] fp32, row = offset(level) + (a*ny + row)*nx + col. */
+ * out is [N, sum_l na*ny*nx, no] fp32, row = offset(level) + (a*ny + row)*nx + col.  na*no <= 1024.
+ * row_max (optional, [N, sum_l na*ny*nx] fp32): for every output row the maximum over classes of
+ * out[.., 5+c] * out[.., 4] (the exact fp32 products); ydet_nms_v5 accepts it in place of its own scan. */
 int ydet_decode_v5(const ydet_v5_level* levels /* host */, int nl, int N, int na, int no,
-                   int grid_transposed, int head_dtype, float* out, void* stream);
+                   int grid_transposed, int head_dtype, float* out, float* row_max, void* stream);
 
 typedef struct {
     const void* head; /* NHWC head map [N, H, W, ld], channels [A conf | A*nc cls | A*4 box] */
@@ -185,14 +187,17 @@ int ydet_decode_v2v3(const ydet_fa_level* levels /* host */, int nl, int N, int 
  * max_nms by score enter the NMS with boxes offset by cls*max_wh (0 if agnostic), all in fp32;
  * at most max_det survive.  class_mask (device, nc bytes, may be NULL) keeps only classes whose
  * byte is non-zero (the `classes=` filter, line 165-166).
+ * row_max (device, [N, nboxes] fp32, may be NULL): per box max_c(pred[5+c] * pred[4]) as written by
+ * ydet_decode_v5 for this very `pred`; it replaces the full scan of pred (the candidates themselves are still
+ * read from pred).  Only valid when every class score is <= 1, as sigmoid outputs are.  Ignored with a class_mask.
  * out_det [N, max_det, 6] = (x1,y1,x2,y2,score,cls) in descending score order, rows >= count zero;
  * out_count [N] int32.  workspace: ydet_nms_v5_workspace_bytes(N, nboxes, no) bytes.
  * Limits: max_nms <= 4096, max_det <= max_nms. */
 size_t ydet_nms_v5_workspace_bytes(int N, int nboxes, int no);
 int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
                 int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
-                const uint8_t* class_mask, float* out_det, int32_t* out_count, void* workspace,
-                size_t workspace_bytes, void* stream);
+                const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
+                void* workspace, size_t workspace_bytes, void* stream);
 
 /* postprocess + nms: utils/utils.py:101-133 and :15-42.
  * boxes [N, n, 4], scores [N, n, nc] fp32.  Per image: cls = argmax (first maximum),

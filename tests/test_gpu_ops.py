@@ -58,6 +58,40 @@ def test_decode_v5_padded_ld():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("nc,dtype", [(80, torch.float32), (3, torch.float32), (100, torch.float32), (80, torch.bfloat16)])
+def test_decode_v5_row_max_and_nms_shortcut(nc, dtype):
+    """decode_v5 also emits per box max_c(cls_c * obj): exact against torch on the decoded tensor, and NMS fed
+    with it returns bit-identical results to NMS that scans the tensor itself.  nc=100 exercises the
+    many-channel (na*no > 256) kernel variant; the maps are non-square."""
+    g = _gen(5, f"rowmax{nc}")
+    no = nc + 5
+    shapes = [(12, 10), (6, 5), (3, 3)]
+    raw = [torch.randn(3, 3 * no, h, w, generator=g) * 2 - 1 for h, w in shapes]
+    heads = [nhwc(r).to(dtype) for r in raw]
+    strides, anchors = [8., 16., 32.], [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+    z = ops.decode_v5(heads, strides, anchors, 3, no)
+    ref, _ = O.detect_decode([h.float().permute(0, 3, 1, 2).cpu().numpy() for h in heads], strides,
+                             np.array(anchors, np.float32).reshape(3, 3, 2), 3, no)
+    np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=3e-6, atol=2e-6)
+    rm = ops.row_max_of(z)
+    assert rm is not None and rm.shape == z.shape[:2]
+    expect = (z[..., 5:] * z[..., 4:5]).max(-1).values
+    assert torch.equal(rm, expect)
+    for kw in (dict(conf_thres=0.001, iou_thres=0.6, multi_label=True), dict(conf_thres=0.25, iou_thres=0.45),
+               dict(conf_thres=0.05, iou_thres=0.5, multi_label=True, max_det=50)):
+        d1, c1 = ops.nms_v5(z, **kw)                    # shortcut: row maxima from the decode kernel
+        d2, c2 = ops.nms_v5(z, row_max=None, **kw)      # full scan
+        assert torch.equal(c1, c2) and torch.equal(d1, d2)
+        want = O.non_max_suppression(z.cpu().numpy(), **kw)
+        for i, w in enumerate(want):
+            np.testing.assert_array_equal(d1[i, : int(c1[i])].cpu().numpy(), w)
+    # the shortcut is dropped as soon as the tensor is modified or replaced
+    z2 = z.clone()
+    assert ops.row_max_of(z2) is None
+    z[0, 0, 4] = 0.5
+    assert ops.row_max_of(z) is None
+
+
 @pytest.mark.parametrize("tag,size,v2", [("v3tiny", 64, False), ("v3tiny", 416, False), ("v2d19", 128, True),
                                          ("v2d19", 416, True), ("v3spp", 128, True), ("v3", 128, False),
                                          ("v4", 128, True)])
@@ -97,7 +131,8 @@ def test_nms_v5_golden(golden, tag):
     _check_nms(_g4_pred(g), [g[f"out{i}"] for i in range(int(g["n_img"]))], **kw)
 
 
-@pytest.mark.parametrize("case", ["ties_all_equal", "ties_threshold_bin", "empty", "one", "classes", "nan_scores"])
+@pytest.mark.parametrize("case", ["ties_all_equal", "ties_threshold_bin", "flat_classes", "empty", "one", "classes",
+                                  "nan_scores"])
 def test_nms_v5_edge_cases(case):
     g = _gen(11, case)
     kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
@@ -111,6 +146,9 @@ def test_nms_v5_edge_cases(case):
         pred = clustered_predictions(2, 6000, 4, seed=9, obj_pass=1.0)
         pred[..., 4] = 0.75
         pred[..., 5:] = 0.5 + torch.rand(2, 6000, 4, generator=g) * 1e-4
+    elif case == "flat_classes":   # every good row carries many candidates of almost the same score
+        pred = clustered_predictions(2, 3000, 20, seed=10, obj_pass=1.0)
+        pred[..., 5:] = 0.5 + torch.rand(2, 3000, 20, generator=g) * 1e-3
     elif case == "empty":
         pred = clustered_predictions(3, 500, 4, seed=3)
         pred[..., 4] = 0.0005

@@ -79,13 +79,13 @@ SYMBOLS = {
     "ydet_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "ydet_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "ydet_decode_v5": (C.c_int, [C.POINTER(V5Level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_void_p, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "ydet_decode_v2v3": (C.c_int, [C.POINTER(FALevel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ydet_nms_v5_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ydet_nms_v5": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                              C.c_size_t, C.c_void_p]),
+                              C.c_void_p, C.c_size_t, C.c_void_p]),
     "ydet_nms_perclass_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ydet_nms_perclass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

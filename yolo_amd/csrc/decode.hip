@@ -19,73 +19,101 @@ struct V5Args {
     const char* head[kMaxLevels];
     int ny[kMaxLevels], nx[kMaxLevels], ld[kMaxLevels];
     int box_off[kMaxLevels + 1];  // first output row of each level; [nl] = rows per image
+    int pix_off[kMaxLevels + 1];  // first pixel of each level; [nl] = pixels per image
     float stride[kMaxLevels];
     float anchor[kMaxLevels][2 * kMaxAnchors];
     int nl, N, na, no, transposed;
     float* out;
-    long long total_boxes;  // N * rows per image
+    float* row_max;       // optional [N][rows per image]
+    long long total_pix;  // N * pixels per image
 };
 
-struct BoxDesc {
-    long long src;  // element offset of channel a*no of this box's pixel in its head map
-    int level;
-    float gx, gy, stride, aw, ah;
-};
-
-constexpr int kBoxesPerBlock = 64;
-
-// One workgroup decodes kBoxesPerBlock consecutive output rows (= kBoxesPerBlock*no contiguous
-// floats of the output).  The per-row index arithmetic is done once per row into LDS; the element
-// loop then only needs one division by `no`.
-template <typename T>
+// One wave decodes whole pixels: the na*no head channels of a pixel are contiguous in the NHWC map, lane l holds
+// channels l, l+64, ... in registers (KR registers cover na*no <= 64*KR), so reads are full contiguous runs and the
+// na output rows of the pixel leave as contiguous runs of `no` floats.  With the pixel in registers, the per-box
+// maximum of class score x objectness is a masked wave reduction.
+template <typename T, int KR, int PPW>
 __global__ __launch_bounds__(256) void decode_v5_kernel(const V5Args a) {
-    __shared__ BoxDesc desc[kBoxesPerBlock];
-    const long long row0 = (long long)blockIdx.x * kBoxesPerBlock;
-    const int rows_per_img = a.box_off[a.nl];
-    if (threadIdx.x < kBoxesPerBlock) {
-        const long long r = row0 + threadIdx.x;
-        BoxDesc d;
-        d.level = -1;
-        if (r < a.total_boxes) {
-            const int n = (int)(r / rows_per_img);
-            const int b = (int)(r - (long long)n * rows_per_img);
-            int l = 0;
-            while (l + 1 < a.nl && b >= a.box_off[l + 1]) ++l;
-            const int lb = b - a.box_off[l];
-            const int hw = a.ny[l] * a.nx[l];
-            const int an = lb / hw;
-            const int cell = lb - an * hw;
-            const int row = cell / a.nx[l], col = cell - row * a.nx[l];
-            d.level = l;
-            d.src = ((long long)((long long)n * a.ny[l] + row) * a.nx[l] + col) * a.ld[l] + (long long)an * a.no;
-            // "transposed": the np.meshgrid(arange(ny), arange(nx)) table of shape (nx, ny) re-read as
-            // (ny, nx): flat cell f holds (f / ny, f % ny) -- (row, col) on square maps.
-            d.gx = a.transposed ? (float)(cell / a.ny[l]) : (float)col;
-            d.gy = a.transposed ? (float)(cell % a.ny[l]) : (float)row;
-            d.stride = a.stride[l];
-            d.aw = a.anchor[l][2 * an];
-            d.ah = a.anchor[l][2 * an + 1];
-        }
-        desc[threadIdx.x] = d;
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int CH = a.na * a.no;
+    const int pix_per_img = a.pix_off[a.nl], rows_per_img = a.box_off[a.nl];
+
+    int an_k[KR], o_k[KR];   // anchor and output column of channel k*64 + lane (pixel independent)
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int ch = k * 64 + lane;
+        int an = 0;
+        while (an + 1 < a.na && ch >= (an + 1) * a.no) ++an;
+        an_k[k] = an;
+        o_k[k] = ch < CH ? ch - an * a.no : -1;
     }
-    __syncthreads();
-    const int nelem = kBoxesPerBlock * a.no;
-    float* out = a.out + row0 * a.no;
-    for (int e = threadIdx.x; e < nelem; e += 256) {
-        const int bl = e / a.no;
-        const int o = e - bl * a.no;
-        const BoxDesc d = desc[bl];
-        if (d.level < 0) break;  // rows past the end: all later e belong to later rows
-        const T* h = reinterpret_cast<const T*>(a.head[d.level]);
-        const float s = sigmoidf_(to_f32(h[d.src + o]));
-        float v = s;
-        if (o < 2) {
-            v = (s * 2.0f - 0.5f + (o == 0 ? d.gx : d.gy)) * d.stride;
-        } else if (o < 4) {
-            const float t = s * 2.0f;
-            v = t * t * (o == 2 ? d.aw : d.ah);
+
+    const T* hp[PPW];
+    int lv[PPW], cellv[PPW], nv[PPW];
+    float raw[PPW][KR];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const long long g = wave * PPW + i;
+        lv[i] = -1;
+        if (g >= a.total_pix) continue;
+        const int n = (int)(g / pix_per_img);
+        const int pi = (int)(g - (long long)n * pix_per_img);
+        int l = 0;
+        while (l + 1 < a.nl && pi >= a.pix_off[l + 1]) ++l;
+        const int cell = pi - a.pix_off[l];
+        lv[i] = l; cellv[i] = cell; nv[i] = n;
+        hp[i] = reinterpret_cast<const T*>(a.head[l]) + ((long long)n * a.ny[l] * a.nx[l] + cell) * a.ld[l];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) raw[i][k] = o_k[k] >= 0 ? to_f32(hp[i][k * 64 + lane]) : 0.f;
+    }
+
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int l = lv[i];
+        if (l < 0) continue;   // wave-uniform
+        const int cell = cellv[i];
+        const int nx = a.nx[l], ny = a.ny[l];
+        const int row = cell / nx, col = cell - row * nx;
+        // "transposed": the np.meshgrid(arange(ny), arange(nx)) table of shape (nx, ny) re-read as (ny, nx):
+        // flat cell f holds (f / ny, f % ny) -- (row, col) on square maps.
+        const float gx = a.transposed ? (float)(cell / ny) : (float)col;
+        const float gy = a.transposed ? (float)(cell % ny) : (float)row;
+        const float stride = a.stride[l];
+        const long long orow0 = (long long)nv[i] * rows_per_img + a.box_off[l] + cell;   // + an*ny*nx
+        float v[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int o = o_k[k];
+            if (o < 0) { v[k] = 0.f; continue; }
+            const int an = an_k[k];
+            const float s = sigmoidf_(raw[i][k]);
+            float val = s;
+            if (o < 2) {
+                val = (s * 2.0f - 0.5f + (o == 0 ? gx : gy)) * stride;
+            } else if (o < 4) {
+                const float t = s * 2.0f;
+                val = t * t * a.anchor[l][2 * an + (o - 2)];
+            }
+            v[k] = val;
+            a.out[(orow0 + (long long)an * ny * nx) * a.no + o] = val;
         }
-        out[e] = v;
+        if (a.row_max) {
+            for (int an = 0; an < a.na; ++an) {
+                const int ca = an * a.no + 4;
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < KR; ++k) t = (ca >> 6) == k ? v[k] : t;
+                const float obj = __shfl(t, ca & 63);
+                float m = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KR; ++k)
+                    if (an_k[k] == an && o_k[k] >= 5) m = fmaxf(m, v[k] * obj);
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+                if (lane == 0) a.row_max[orow0 + (long long)an * ny * nx] = m;
+            }
+        }
     }
 }
 
@@ -156,34 +184,43 @@ __global__ __launch_bounds__(256) void decode_fa_kernel(const FAArgs a) {
 }  // namespace
 
 extern "C" int ydet_decode_v5(const ydet_v5_level* levels, int nl, int N, int na, int no, int grid_transposed,
-                              int head_dtype, float* out, void* stream) {
+                              int head_dtype, float* out, float* row_max, void* stream) {
     clear_error();
     YDET_CHECK_ARG(levels && out, "decode_v5: null pointer");
     YDET_CHECK_ARG(nl >= 1 && nl <= kMaxLevels, "decode_v5: nl=%d (1..%d)", nl, kMaxLevels);
     YDET_CHECK_ARG(na >= 1 && na <= kMaxAnchors, "decode_v5: na=%d (1..%d)", na, kMaxAnchors);
     YDET_CHECK_ARG(N > 0 && no >= 5, "decode_v5: N=%d no=%d", N, no);
+    YDET_CHECK_ARG((long long)na * no <= 1024, "decode_v5: na*no=%lld exceeds 1024", (long long)na * no);
     YDET_CHECK_ARG(dtype_ok(head_dtype), "decode_v5: bad dtype");
     V5Args a;
-    a.nl = nl; a.N = N; a.na = na; a.no = no; a.transposed = grid_transposed ? 1 : 0; a.out = out;
-    long long off = 0;
+    a.nl = nl; a.N = N; a.na = na; a.no = no; a.transposed = grid_transposed ? 1 : 0; a.out = out; a.row_max = row_max;
+    long long off = 0, pix = 0;
     for (int l = 0; l < nl; ++l) {
         const ydet_v5_level& L = levels[l];
         YDET_CHECK_ARG(L.head && L.ny > 0 && L.nx > 0 && L.ld >= na * no, "decode_v5: level %d shape", l);
         a.head[l] = (const char*)L.head; a.ny[l] = L.ny; a.nx[l] = L.nx; a.ld[l] = L.ld; a.stride[l] = L.stride;
         for (int i = 0; i < 2 * kMaxAnchors; ++i) a.anchor[l][i] = i < 2 * na ? L.anchor_wh[i] : 0.f;
         a.box_off[l] = (int)off;
+        a.pix_off[l] = (int)pix;
         off += (long long)na * L.ny * L.nx;
+        pix += (long long)L.ny * L.nx;
         YDET_CHECK_ARG(off < (1LL << 30), "decode_v5: too many boxes per image");
     }
-    for (int l = nl; l <= kMaxLevels; ++l) a.box_off[l] = (int)off;
-    a.box_off[nl] = (int)off;
-    a.total_boxes = (long long)N * off;
-    const long long grid = (a.total_boxes + kBoxesPerBlock - 1) / kBoxesPerBlock;
+    for (int l = nl; l <= kMaxLevels; ++l) { a.box_off[l] = (int)off; a.pix_off[l] = (int)pix; }
+    a.total_pix = (long long)N * pix;
+    const bool small = na * no <= 256;
+    const int ppw = small ? 4 : 1;
+    const long long waves = (a.total_pix + ppw - 1) / ppw;
+    const long long grid = (waves + 3) / 4;
     YDET_CHECK_ARG(grid > 0 && grid < 0x7fffffffLL, "decode_v5: grid");
-    if (head_dtype == YDET_BF16)
-        hipLaunchKernelGGL(decode_v5_kernel<__bf16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
-    else
-        hipLaunchKernelGGL(decode_v5_kernel<float>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    hipStream_t s = as_stream(stream);
+    if (head_dtype == YDET_BF16) {
+        if (small) hipLaunchKernelGGL((decode_v5_kernel<__bf16, 4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((decode_v5_kernel<__bf16, 16, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else {
+        if (small) hipLaunchKernelGGL((decode_v5_kernel<float, 4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((decode_v5_kernel<float, 16, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    }
     YDET_CHECK_LAUNCH("decode_v5_kernel");
     return YDET_OK;
 }

@@ -133,11 +133,14 @@ __device__ void greedy_nms_block(int ns, float thr, LoadBox load, NmsShared& sh,
 constexpr int kHistBins = 2048;
 constexpr int kListCap = 4096;   // candidates kept for the final sort (>= max_nms)
 constexpr int kMaxNms = 4096;
-constexpr int kTileFloats = 8192;  // LDS staging tile of prediction rows
+constexpr int kTileFloats = 8192;  // LDS staging tile of prediction rows (exact-select path)
+constexpr int kScanRows = 128;     // rows per workgroup of the row-maximum scan
+constexpr int kScanTile = 11008;   // floats of its LDS tile (128 rows of 85 + slack)
+constexpr int kPickThreads = 1024;
 
 struct V5Meta {  // per image, 16 words
-    unsigned total;       // candidates above conf
-    unsigned thr_bin;     // lowest histogram bin that enters the list
+    unsigned total;       // rows (boxes) with at least one candidate above conf
+    unsigned thr_bin;     // lowest score bin that enters the list
     unsigned list_count;  // entries appended to the list
     unsigned overflow;    // list would exceed kListCap: exact select path
     unsigned ns;          // sorted candidates entering the NMS
@@ -146,14 +149,15 @@ struct V5Meta {  // per image, 16 words
 
 struct V5Args {
     const float* pred;
-    int N, nboxes, no, nc, rows_per_block;
+    int N, nboxes, no, nc, rows_per_block, scan_rows;
     float conf, iou;
     int multi, agnostic, max_nms, max_det;
     float max_wh;
     const uint8_t* class_mask;
     unsigned base16;  // (orderable(conf) >> 16)
+    const float* row_max;  // [N][nboxes]: max over classes of cls*obj (-inf: no candidate); caller's or workspace
     // workspace
-    unsigned* hist;   // [N][kHistBins]
+    float* row_max_ws;     // [N][nboxes]
     V5Meta* meta;     // [N]
     u64* list;        // [N][kListCap]
     u64* sorted;      // [N][kMaxNms]
@@ -205,77 +209,174 @@ __device__ __forceinline__ void v5_visit(const V5Args& a, const float* img, int 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void v5_hist_kernel(const V5Args a) {
-    __shared__ float tile[kTileFloats];
-    __shared__ unsigned lhist[kHistBins];
+// Row maxima: for every box the largest cls*obj over the (unmasked) classes, -inf when obj <= conf.  One pass over
+// the predictions; 128 rows per workgroup staged through LDS (row pitch `no` floats: an odd pitch such as 85 makes
+// the per-row walks below bank-conflict free), two threads per row.
+__global__ __launch_bounds__(256) void v5_rowmax_kernel(const V5Args a) {
+    __shared__ __attribute__((aligned(16))) float tile[kScanTile];
     const int img = blockIdx.y;
-    const int row0 = blockIdx.x * a.rows_per_block;
-    const int rows = min(a.rows_per_block, a.nboxes - row0);
-    for (int i = threadIdx.x; i < kHistBins; i += 256) lhist[i] = 0;
-    __syncthreads();
-    const unsigned base16 = a.base16;
-    v5_visit(a, a.pred + (size_t)img * a.nboxes * a.no, row0, rows, tile,
-             [&](unsigned, float s) { atomicAdd(&lhist[score_bin(s, base16)], 1u); });
-    unsigned* gh = a.hist + (size_t)img * kHistBins;
-    for (int i = threadIdx.x; i < kHistBins; i += 256) {
-        const unsigned v = lhist[i];
-        if (v) atomicAdd(&gh[i], v);
+    const int row0 = blockIdx.x * a.scan_rows;
+    const int rows = min(a.scan_rows, a.nboxes - row0);
+    const int nelem = rows * a.no;
+    const float* src = a.pred + ((size_t)img * a.nboxes + row0) * a.no;
+    if (((uintptr_t)src & 15) == 0) {
+        const int nv = nelem >> 2;
+        for (int i = threadIdx.x; i < nv; i += 256)
+            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (int e = (nv << 2) + threadIdx.x; e < nelem; e += 256) tile[e] = src[e];
+    } else {
+        for (int e = threadIdx.x; e < nelem; e += 256) tile[e] = src[e];
     }
+    __syncthreads();
+    const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
+    float m = -INFINITY, obj = 0.f;
+    if (r < rows) {
+        const float* p = tile + r * a.no;
+        obj = p[4];
+        const int c0 = half ? a.nc >> 1 : 0, c1 = half ? a.nc : a.nc >> 1;
+        if (a.class_mask) {
+            for (int c = c0; c < c1; ++c)
+                if (a.class_mask[c]) m = fmaxf(m, p[5 + c] * obj);
+        } else {
+            for (int c = c0; c < c1; ++c) m = fmaxf(m, p[5 + c] * obj);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 1));
+    if (r < rows && half == 0) a.row_max_ws[(size_t)img * a.nboxes + row0 + r] = obj > a.conf ? m : -INFINITY;
 }
 
-// One workgroup per image: lowest bin b with sum_{i>=b} hist[i] >= max_nms (b = 0 if the total is
-// smaller), i.e. every candidate of the top max_nms lies in bins >= b.
-__global__ __launch_bounds__(256) void v5_select_kernel(const V5Args a) {
-    __shared__ unsigned part[256];
-    const int img = blockIdx.x;
-    const unsigned* gh = a.hist + (size_t)img * kHistBins;
-    unsigned loc[8], s = 0;
-    for (int i = 0; i < 8; ++i) { loc[i] = gh[threadIdx.x * 8 + i]; s += loc[i]; }
-    part[threadIdx.x] = s;
+// Lowest bin b with sum_{i>=b} hist[i] >= want (0 when the total is smaller); called by every thread of the
+// workgroup, which must be at least 256 wide.  part: 256 words of scratch.  *total_out: sum of all bins.
+__device__ unsigned select_bin(const unsigned* hist, unsigned* part, unsigned* s_out, unsigned want, unsigned* total_out) {
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        unsigned s = 0;
+        for (int i = 0; i < 8; ++i) s += hist[tid * 8 + i];
+        part[tid] = s;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         unsigned total = 0;
         for (int i = 0; i < 256; ++i) total += part[i];
-        unsigned thr_bin = 0, in_list = total;
-        if (total > (unsigned)a.max_nms) {
+        unsigned thr_bin = 0;
+        if (total > want) {
             unsigned acc = 0;
             int t = 255;
             for (; t >= 0; --t) {
-                if (acc + part[t] >= (unsigned)a.max_nms) break;
+                if (acc + part[t] >= want) break;
                 acc += part[t];
             }
             int b = t * 8 + 7;
             for (;; --b) {
-                acc += gh[b];
-                if (acc >= (unsigned)a.max_nms || b == t * 8) break;
+                acc += hist[b];
+                if (acc >= want || b == t * 8) break;
             }
             thr_bin = (unsigned)b;
-            in_list = acc;
         }
-        V5Meta& m = a.meta[img];
-        m.total = total;
-        m.thr_bin = thr_bin;
-        m.list_count = 0;
-        m.overflow = in_list > (unsigned)kListCap ? 1u : 0u;
-        m.ns = 0;
+        s_out[0] = thr_bin;
+        s_out[1] = total;
     }
+    __syncthreads();
+    if (total_out) *total_out = s_out[1];
+    return s_out[0];
 }
 
-__global__ __launch_bounds__(256) void v5_collect_kernel(const V5Args a) {
-    __shared__ float tile[kTileFloats];
-    const int img = blockIdx.y;
-    V5Meta* m = a.meta + img;
-    if (m->overflow || m->total == 0) return;
-    const int row0 = blockIdx.x * a.rows_per_block;
-    const int rows = min(a.rows_per_block, a.nboxes - row0);
-    const unsigned base16 = a.base16, thr_bin = m->thr_bin;
+// One workgroup per image.  (1) histogram of the row maxima above conf and the lowest bin b such that at least
+// max_nms rows lie in bins >= b: each such row owns a candidate that good, so the max_nms best candidates all lie
+// in bins >= b.  (2) rows in bins >= b are queued (a queue longer than the candidate list means the list would
+// overflow too).  (3) the queued rows' candidates -- yolov5_official/utils.py:122 (obj > conf), :151 (cls *= obj),
+// :157-159 (every class above conf) or :160-162 (best class) -- are histogrammed the same way, which gives the
+// final bin b2 >= b, and those in bins >= b2 go to the list.
+__global__ __launch_bounds__(kPickThreads) void v5_pick_kernel(const V5Args a) {
+    __shared__ unsigned hist[kHistBins];
+    __shared__ unsigned part[256];
+    __shared__ unsigned queue[kListCap];
+    __shared__ unsigned s_sel[2], s_nq, s_count;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const float* rm = a.row_max + (size_t)img * a.nboxes;
+    const unsigned base16 = a.base16;
+    for (int i = tid; i < kHistBins; i += kPickThreads) hist[i] = 0;
+    if (tid == 0) { s_nq = 0; s_count = 0; }
+    __syncthreads();
+    for (int r = tid; r < a.nboxes; r += kPickThreads) {
+        const float v = rm[r];
+        if (v > a.conf) atomicAdd(&hist[score_bin(v, base16)], 1u);
+    }
+    __syncthreads();
+    unsigned total_rows;
+    const unsigned row_bin = select_bin(hist, part, s_sel, (unsigned)a.max_nms, &total_rows);
+    for (int r = tid; r < a.nboxes; r += kPickThreads) {
+        const float v = rm[r];
+        if (v > a.conf && score_bin(v, base16) >= row_bin) {
+            const unsigned pos = atomicAdd(&s_nq, 1u);
+            if (pos < (unsigned)kListCap) queue[pos] = (unsigned)r;
+        }
+    }
+    for (int i = tid; i < kHistBins; i += kPickThreads) hist[i] = 0;
+    __syncthreads();
+    V5Meta& m = a.meta[img];
+    const unsigned nq = s_nq;
+    if (nq > (unsigned)kListCap) {   // workgroup-uniform
+        if (tid == 0) { m.total = total_rows; m.thr_bin = row_bin; m.ns = 0; m.list_count = 0; m.overflow = 1; }
+        return;
+    }
+    const float* pimg = a.pred + (size_t)img * a.nboxes * a.no;
     u64* list = a.list + (size_t)img * kListCap;
-    v5_visit(a, a.pred + (size_t)img * a.nboxes * a.no, row0, rows, tile, [&](unsigned idx, float s) {
-        if (score_bin(s, base16) >= thr_bin) {
-            const unsigned pos = atomicAdd(&m->list_count, 1u);
-            if (pos < (unsigned)kListCap) list[pos] = ((u64)f2key(s) << 32) | (u64)(0xFFFFFFFFu - idx);
+    // visit(row, cls, score) for every candidate of the queued rows
+    auto for_candidates = [&](auto visit) {
+        if (a.multi) {
+            const unsigned npair = nq * (unsigned)a.nc;
+            for (unsigned p = tid; p < npair; p += kPickThreads) {
+                const unsigned q = p / (unsigned)a.nc;
+                const int c = (int)(p - q * (unsigned)a.nc);
+                const unsigned row = queue[q];
+                const float* pr = pimg + (size_t)row * a.no;
+                const float obj = pr[4];
+                if (!(obj > a.conf)) continue;
+                const float sc = pr[5 + c] * obj;
+                if (!(sc > a.conf)) continue;
+                if (a.class_mask && !a.class_mask[c]) continue;
+                visit(row, c, sc);
+            }
+        } else {
+            for (unsigned q = tid; q < nq; q += kPickThreads) {
+                const unsigned row = queue[q];
+                const float* pr = pimg + (size_t)row * a.no;
+                const float obj = pr[4];
+                if (!(obj > a.conf)) continue;
+                float best = pr[5] * obj;
+                int bj = 0;
+                for (int j = 1; j < a.nc; ++j) {
+                    const float v = pr[5 + j] * obj;
+                    if (v > best) { best = v; bj = j; }
+                }
+                if (!(best > a.conf)) continue;
+                if (a.class_mask && !a.class_mask[bj]) continue;
+                visit(row, bj, best);
+            }
+        }
+    };
+    for_candidates([&](unsigned, int, float sc) {
+        const unsigned b = score_bin(sc, base16);
+        if (b >= row_bin) atomicAdd(&hist[b], 1u);
+    });
+    __syncthreads();
+    const unsigned thr_bin = select_bin(hist, part, s_sel, (unsigned)a.max_nms, nullptr);
+    for_candidates([&](unsigned row, int cls, float sc) {
+        if (score_bin(sc, base16) >= thr_bin && score_bin(sc, base16) >= row_bin) {
+            const unsigned pos = atomicAdd(&s_count, 1u);
+            if (pos < (unsigned)kListCap)
+                list[pos] = ((u64)f2key(sc) << 32) | (u64)(0xFFFFFFFFu - (row * (unsigned)a.nc + (unsigned)cls));
         }
     });
+    __syncthreads();
+    if (tid == 0) {
+        m.total = total_rows;
+        m.thr_bin = thr_bin;
+        m.ns = 0;
+        m.list_count = s_count;
+        m.overflow = s_count > (unsigned)kListCap ? 1u : 0u;
+    }
 }
 
 // Exact path for images whose threshold bin holds more than kListCap candidates (heavy score ties):
@@ -413,10 +514,11 @@ __global__ __launch_bounds__(256) void v5_nms_kernel(const V5Args a) {
     if (threadIdx.x == 0) a.out_count[img] = count;
 }
 
-size_t v5_ws_layout(int N, size_t* o_hist, size_t* o_meta, size_t* o_list, size_t* o_sorted, size_t* o_sbox) {
+size_t v5_ws_layout(int N, int nboxes, size_t* o_hist, size_t* o_meta, size_t* o_list, size_t* o_sorted,
+                    size_t* o_sbox) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
-    const size_t h = take((size_t)N * kHistBins * sizeof(unsigned));
+    const size_t h = take((size_t)N * nboxes * sizeof(float));   // row maxima
     const size_t m = take((size_t)N * sizeof(V5Meta));
     const size_t l = take((size_t)N * kListCap * sizeof(u64));
     const size_t s = take((size_t)N * kMaxNms * sizeof(u64));
@@ -557,26 +659,27 @@ __global__ void box_iou_kernel(const float4* a, int na, const float4* b, int nb,
 }  // namespace
 
 extern "C" size_t ydet_nms_v5_workspace_bytes(int N, int nboxes, int no) {
-    (void)nboxes; (void)no;
-    if (N <= 0) return 0;
-    return v5_ws_layout(N, nullptr, nullptr, nullptr, nullptr, nullptr);
+    (void)no;
+    if (N <= 0 || nboxes <= 0) return 0;
+    return v5_ws_layout(N, nboxes, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
                            int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
-                           const uint8_t* class_mask, float* out_det, int32_t* out_count, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+                           const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     clear_error();
     YDET_CHECK_ARG(pred && out_det && out_count && workspace, "nms_v5: null pointer");
     YDET_CHECK_ARG(N > 0 && nboxes > 0 && no >= 6, "nms_v5: N=%d nboxes=%d no=%d", N, nboxes, no);
     YDET_CHECK_ARG(no <= kTileFloats, "nms_v5: no=%d exceeds %d", no, kTileFloats);
+    YDET_CHECK_ARG(((uintptr_t)pred & 3) == 0, "nms_v5: pred must be 4-byte aligned");
     YDET_CHECK_ARG(max_nms >= 1 && max_nms <= kMaxNms, "nms_v5: max_nms=%d (1..%d)", max_nms, kMaxNms);
     YDET_CHECK_ARG(max_det >= 1 && max_det <= max_nms, "nms_v5: max_det=%d (1..max_nms)", max_det);
     const int nc = no - 5;
     YDET_CHECK_ARG((long long)nboxes * nc < 0xFFFFFFFFLL, "nms_v5: nboxes*nc does not fit 32 bits");
     YDET_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "nms_v5: workspace must be 256-byte aligned");
     size_t oh, om, ol, os, ob;
-    const size_t need = v5_ws_layout(N, &oh, &om, &ol, &os, &ob);
+    const size_t need = v5_ws_layout(N, nboxes, &oh, &om, &ol, &os, &ob);
     if (workspace_bytes < need) return fail(YDET_ERR_WORKSPACE, "nms_v5: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = as_stream(stream);
     char* ws = (char*)workspace;
@@ -584,21 +687,24 @@ extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float c
     a.pred = pred; a.N = N; a.nboxes = nboxes; a.no = no; a.nc = nc;
     a.rows_per_block = kTileFloats / no;
     if (a.rows_per_block > 128) a.rows_per_block = 128;
+    a.scan_rows = kScanTile / no < kScanRows ? kScanTile / no : kScanRows;
     a.conf = conf_thres; a.iou = iou_thres;
     a.multi = (multi_label && nc > 1) ? 1 : 0;
     a.agnostic = agnostic ? 1 : 0;
     a.max_nms = max_nms; a.max_det = max_det; a.max_wh = max_wh; a.class_mask = class_mask;
     a.base16 = f2key_host(conf_thres) >> 16;
-    a.hist = (unsigned*)(ws + oh); a.meta = (V5Meta*)(ws + om); a.list = (u64*)(ws + ol);
+    a.row_max_ws = (float*)(ws + oh); a.meta = (V5Meta*)(ws + om); a.list = (u64*)(ws + ol);
+    // a caller-supplied row maximum is over all classes: with a class filter the scan has to run
+    const bool scan = row_max == nullptr || class_mask != nullptr;
+    a.row_max = scan ? a.row_max_ws : row_max;
     a.sorted = (u64*)(ws + os); a.sbox = (float4*)(ws + ob);
     a.out_det = out_det; a.out_count = out_count;
-    if (hipMemsetAsync(ws + oh, 0, om + (size_t)N * sizeof(V5Meta) - oh, s) != hipSuccess)
-        return fail(YDET_ERR_LAUNCH, "nms_v5: hipMemsetAsync failed");
-    const dim3 grid2((unsigned)((nboxes + a.rows_per_block - 1) / a.rows_per_block), (unsigned)N);
     YDET_CHECK_ARG(N <= 65535, "nms_v5: N=%d exceeds 65535", N);
-    hipLaunchKernelGGL(v5_hist_kernel, grid2, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(v5_select_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(v5_collect_kernel, grid2, dim3(256), 0, s, a);
+    if (scan) {
+        const dim3 grid2((unsigned)((nboxes + a.scan_rows - 1) / a.scan_rows), (unsigned)N);
+        hipLaunchKernelGGL(v5_rowmax_kernel, grid2, dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(v5_pick_kernel, dim3((unsigned)N), dim3(kPickThreads), 0, s, a);
     hipLaunchKernelGGL(v5_exact_select_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(v5_rank_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(v5_nms_kernel, dim3((unsigned)N), dim3(256), 0, s, a);

@@ -24,10 +24,12 @@ def _need_cuda(*ts):
             raise RuntimeError("yolo_amd GPU operator called with a CPU tensor (there is no CPU path here)")
 
 
-def decode_v5(heads, strides, anchors_px, na, no, grid_transposed=False):
+def decode_v5(heads, strides, anchors_px, na, no, grid_transposed=False, row_max=True):
     """heads: NHWC maps [N, ny, nx, >=na*no] (fp32 or bf16, last dim contiguous), one per level.
     strides: per-level float; anchors_px: per-level list of 2*na pixel sizes.
-    Returns z [N, sum(na*ny*nx), no] fp32 (yolov5_official/model.py:56-81)."""
+    Returns z [N, sum(na*ny*nx), no] fp32 (yolov5_official/model.py:56-81).
+    With row_max, the kernel also emits per box max_c(cls_c * obj); it rides on the result as `z._ydet_row_max`
+    (tensor, version of z) and lets nms_v5 skip its scan of z while z stays unmodified."""
     _need_cuda(*heads)
     lib = _ffi.lib()
     nl = len(heads)
@@ -44,10 +46,25 @@ def decode_v5(heads, strides, anchors_px, na, no, grid_transposed=False):
             L.anchor_wh[i] = float(v)
         rows += na * h.shape[1] * h.shape[2]
     out = torch.empty(N, rows, no, device=heads[0].device, dtype=torch.float32)
+    rm = torch.empty(N, rows, device=out.device, dtype=torch.float32) if row_max and no > 5 else None
     with torch.cuda.device(out.device):
         _ffi.check(lib.ydet_decode_v5(levels, nl, N, na, no, int(grid_transposed), _dt(heads[0]), out.data_ptr(),
-                                      _ffi.current_stream()), "ydet_decode_v5")
+                                      rm.data_ptr() if rm is not None else None, _ffi.current_stream()),
+                   "ydet_decode_v5")
+    if rm is not None:
+        out._ydet_row_max = (rm, out._version)
     return out
+
+
+def row_max_of(pred):
+    """The row maxima decode_v5 attached to `pred`, if `pred` is still that very tensor, unmodified."""
+    hint = getattr(pred, "_ydet_row_max", None)
+    if hint is None:
+        return None
+    rm, version = hint
+    if version != pred._version or rm.shape != pred.shape[:2] or rm.device != pred.device:
+        return None
+    return rm
 
 
 def decode_v2v3(heads, anchors, A, nc, mode, input_size, mult=32.0, grid_transposed=True):
@@ -79,11 +96,15 @@ def decode_v2v3(heads, anchors, A, nc, mode, input_size, mult=32.0, grid_transpo
 
 
 def nms_v5(pred, conf_thres=0.25, iou_thres=0.45, multi_label=False, agnostic=False, max_det=300, max_nms=None,
-           max_wh=4096.0, classes=None):
+           max_wh=4096.0, classes=None, row_max="auto"):
     """pred [N, nboxes, 5+nc] fp32 CUDA.  Returns (det [N, max_det, 6], count [N] int32) on the device;
-    det rows are (x1, y1, x2, y2, score, cls) in descending score order."""
+    det rows are (x1, y1, x2, y2, score, cls) in descending score order.
+    row_max: "auto" uses the row maxima decode_v5 attached to `pred` (if still valid), None forces the scan."""
     _need_cuda(pred)
     lib = _ffi.lib()
+    rm = row_max_of(pred) if isinstance(row_max, str) else row_max
+    if pred.dtype != torch.float32 or not pred.is_contiguous():
+        rm = None
     if pred.dtype != torch.float32:
         pred = pred.float()
     pred = pred.contiguous()
@@ -105,8 +126,9 @@ def nms_v5(pred, conf_thres=0.25, iou_thres=0.45, multi_label=False, agnostic=Fa
     with torch.cuda.device(dev):
         _ffi.check(lib.ydet_nms_v5(pred.data_ptr(), N, nboxes, no, float(conf_thres), float(iou_thres),
                                    int(bool(multi_label)), int(bool(agnostic)), int(max_nms), int(max_det),
-                                   float(max_wh), mask_ptr, det.data_ptr(), count.data_ptr(), ws.data_ptr(),
-                                   ws_bytes, _ffi.current_stream()), "ydet_nms_v5")
+                                   float(max_wh), mask_ptr, rm.data_ptr() if rm is not None else None,
+                                   det.data_ptr(), count.data_ptr(), ws.data_ptr(), ws_bytes,
+                                   _ffi.current_stream()), "ydet_nms_v5")
     return det, count
 
 

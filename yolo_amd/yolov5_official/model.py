@@ -86,8 +86,14 @@ class Detect(nn.Module):
 
     def decode(self, heads):
         """heads: NHWC fp32 maps [N, ny, nx, na*no] -> (z, [x_i]) as the reference returns them."""
-        strides = [float(s) for s in self.stride]
-        anchors = self.anchor_grid.detach().float().cpu().view(self.nl, -1).tolist()
+        # host copies of stride / anchor_grid, refreshed when the buffer changes (reading them from the device
+        # on every call would stall the stream)
+        ver = (self.anchor_grid._version, self.anchor_grid.data_ptr(), tuple(float(s) for s in self.stride))
+        cached = self.__dict__.get("_ydet_anchor_host")
+        if cached is None or cached[0] != ver:
+            cached = (ver, self.anchor_grid.detach().float().cpu().view(self.nl, -1).tolist())
+            self.__dict__["_ydet_anchor_host"] = cached
+        strides, anchors = list(ver[2]), cached[1]
         z = ops.decode_v5(heads, strides, anchors, self.na, self.no, self.grid_transposed)
         xs = [h.view(h.shape[0], h.shape[1], h.shape[2], self.na, self.no).permute(0, 3, 1, 2, 4) for h in heads]
         return z, xs
