@@ -151,7 +151,7 @@ typedef struct {
  * holds the offset (col, row)) and models/yolo.py:42-71 (grid_transposed = 1: its np.meshgrid table makes
  * flat cell f = row*nx + col hold (f / ny, f % ny), which is (row, col) on square maps).
  *   s = sigmoid(raw); xy = (2 s - 0.5 + grid) * stride; wh = (2 s)^2 * anchor; rest = s
- * out is [N, sum_l na*ny*nx, no] fp32, row = offset(level) + (a*ny + row)*nx + col.  na*no <= 1024.
+ * out is [N, sum_l na*ny*nx, no] fp32, row = offset(level) + (a*ny + row)*nx + col.  no <= 1024.
  * row_max (optional, [N, sum_l na*ny*nx] fp32): for every output row the maximum over classes of
  * out[.., 5+c] * out[.., 4] (the exact fp32 products); ydet_nms_v5 accepts it in place of its own scan. */
 int ydet_decode_v5(const ydet_v5_level* levels /* host */, int nl, int N, int na, int no,

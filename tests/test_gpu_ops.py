@@ -58,20 +58,22 @@ def test_decode_v5_padded_ld():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("nc,dtype", [(80, torch.float32), (3, torch.float32), (100, torch.float32), (80, torch.bfloat16)])
-def test_decode_v5_row_max_and_nms_shortcut(nc, dtype):
+@pytest.mark.parametrize("nc,dtype,na", [(80, torch.float32, 3), (3, torch.float32, 3), (200, torch.float32, 3),
+                                         (80, torch.bfloat16, 3), (20, torch.float32, 2), (7, torch.float32, 5)])
+def test_decode_v5_row_max_and_nms_shortcut(nc, dtype, na):
     """decode_v5 also emits per box max_c(cls_c * obj): exact against torch on the decoded tensor, and NMS fed
-    with it returns bit-identical results to NMS that scans the tensor itself.  nc=100 exercises the
-    many-channel (na*no > 256) kernel variant; the maps are non-square."""
+    with it returns bit-identical results to NMS that scans the tensor itself.  nc=200 exercises the
+    wide-row (no > 128) kernel variant, na != 3 the generic anchor loop; the maps are non-square."""
     g = _gen(5, f"rowmax{nc}")
     no = nc + 5
     shapes = [(12, 10), (6, 5), (3, 3)]
-    raw = [torch.randn(3, 3 * no, h, w, generator=g) * 2 - 1 for h, w in shapes]
+    raw = [torch.randn(3, na * no, h, w, generator=g) * 2 - 1 for h, w in shapes]
     heads = [nhwc(r).to(dtype) for r in raw]
-    strides, anchors = [8., 16., 32.], [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
-    z = ops.decode_v5(heads, strides, anchors, 3, no)
+    strides = [8., 16., 32.]
+    anchors = (torch.rand(3, 2 * na, generator=g) * 100 + 5).tolist()
+    z = ops.decode_v5(heads, strides, anchors, na, no)
     ref, _ = O.detect_decode([h.float().permute(0, 3, 1, 2).cpu().numpy() for h in heads], strides,
-                             np.array(anchors, np.float32).reshape(3, 3, 2), 3, no)
+                             np.array(anchors, np.float32).reshape(3, na, 2), na, no)
     np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=3e-6, atol=2e-6)
     rm = ops.row_max_of(z)
     assert rm is not None and rm.shape == z.shape[:2]

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Calibration: what stock elementwise kernels reach on this GPU for a 550 MB fp32 copy / sigmoid / fill."""
+import torch
+dev = "cuda:0"
+n = 64 * 25200 * 85
+x = torch.randn(n, device=dev)
+y = torch.empty_like(x)
+
+def timeit(fn, k=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / k * 1e3
+
+for name, fn, nb in (("copy", lambda: y.copy_(x), 8 * n), ("sigmoid", lambda: torch.sigmoid(x, out=y), 8 * n),
+                     ("fill", lambda: y.fill_(1.0), 4 * n), ("sum", lambda: x.sum(), 4 * n)):
+    t = timeit(fn)
+    print(f"{name}: {t:.0f} us  {nb / t / 1e6:.2f} TB/s")

@@ -1,6 +1,8 @@
 // Box decode kernels (gfx950).  Both are HBM-bound: every head value is read once and every decoded
 // value written once.  Compiled with -ffp-contract=off so that the arithmetic keeps the operation
 // order of the Python expressions it replaces.
+#include <type_traits>
+
 #include "ydet_internal.h"
 
 using namespace ydet;
@@ -11,108 +13,152 @@ constexpr int kMaxLevels = 4;
 constexpr int kMaxAnchors = 8;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32): relative error below 1e-6 for |x| < 16, absolute error below
+// 1e-8 beyond; about 5 instructions instead of 25
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
+// max over the 64 lanes of a wave, returned in every lane: four DPP steps inside each row of 16 lanes, then the
+// four row results are combined as scalars.
+__device__ __forceinline__ float wave_max(float v) {
+    auto step = [](float x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false);
+        return fmaxf(x, __int_as_float(y));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 
 // --------------------------------------------------------------------------------------------------
 // YOLOv5 Detect decode.
 // --------------------------------------------------------------------------------------------------
-struct V5Args {
-    const char* head[kMaxLevels];
-    int ny[kMaxLevels], nx[kMaxLevels], ld[kMaxLevels];
-    int box_off[kMaxLevels + 1];  // first output row of each level; [nl] = rows per image
-    int pix_off[kMaxLevels + 1];  // first pixel of each level; [nl] = pixels per image
-    float stride[kMaxLevels];
-    float anchor[kMaxLevels][2 * kMaxAnchors];
-    int nl, N, na, no, transposed;
-    float* out;
-    float* row_max;       // optional [N][rows per image]
-    long long total_pix;  // N * pixels per image
+struct V5LevelArgs {   // one launch per pyramid level
+    const char* head;   // NHWC [N][ny*nx][ld]
+    float* out;         // first output row of this level in image 0
+    float* row_max;     // same for the optional row maxima (or null)
+    int ny, nx, ld, hw; // hw = ny*nx
+    int na, no, transposed;
+    long long rows_per_img;
+    float stride, rd;   // rd = 1/nx (1/ny when transposed)
+    float anchor[2 * kMaxAnchors];
 };
 
-// One wave decodes whole pixels: the na*no head channels of a pixel are contiguous in the NHWC map, lane l holds
-// channels l, l+64, ... in registers (KR registers cover na*no <= 64*KR), so reads are full contiguous runs and the
-// na output rows of the pixel leave as contiguous runs of `no` floats.  With the pixel in registers, the per-box
-// maximum of class score x objectness is a masked wave reduction.
-template <typename T, int KR, int PPW>
-__global__ __launch_bounds__(256) void decode_v5_kernel(const V5Args a) {
+// x / d for 0 <= x < 2^22, 0 < d, given rd = 1.0f / d: the float product is off by less than one.
+__device__ __forceinline__ int div_small(int x, int d, float rd) {
+    int q = (int)((float)x * rd);
+    const int r = x - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
+// One wave decodes whole pixels, anchor by anchor: the `no` channels of one (pixel, anchor) are contiguous in the
+// NHWC head map and form one contiguous output row, lane l holds columns l, l+64, ... (OR registers cover
+// no <= 64*OR), so loads and stores are contiguous runs, the column index of a lane never changes, and the per-box
+// maximum of class score x objectness is one masked wave reduction.  PPW pixels x NA anchors are loaded before the
+// first is processed (NA = 0: any anchor count, one anchor's loads in flight at a time).
+template <typename T, int OR, int PPW, int NA>
+__global__ __launch_bounds__(256) void decode_v5_kernel(const V5LevelArgs a) {
+    typedef const T __attribute__((address_space(1)))* in_ptr;      // global address space: no flat instructions
+    typedef float __attribute__((address_space(1)))* out_ptr;
+    constexpr int NAR = NA > 0 ? NA : 1;
     const int lane = threadIdx.x & 63;
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int CH = a.na * a.no;
-    const int pix_per_img = a.pix_off[a.nl], rows_per_img = a.box_off[a.nl];
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.y;
+    const int na = NA > 0 ? NA : a.na;
+    const int no = a.no;
+    const bool col_ok[OR > 1 ? 2 : 1] = {lane < no, OR > 1 ? 64 + lane < no : false};   // registers 0 and 1
 
-    int an_k[KR], o_k[KR];   // anchor and output column of channel k*64 + lane (pixel independent)
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-        const int ch = k * 64 + lane;
-        int an = 0;
-        while (an + 1 < a.na && ch >= (an + 1) * a.no) ++an;
-        an_k[k] = an;
-        o_k[k] = ch < CH ? ch - an * a.no : -1;
-    }
-
-    const T* hp[PPW];
-    int lv[PPW], cellv[PPW], nv[PPW];
-    float raw[PPW][KR];
+    in_ptr hp[PPW];
+    out_ptr op[PPW], mp[PPW];
+    bool live[PPW];
+    float g_l[PPW];   // grid offset of this lane's column (lane 0: x, lane 1: y)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const long long g = wave * PPW + i;
-        lv[i] = -1;
-        if (g >= a.total_pix) continue;
-        const int n = (int)(g / pix_per_img);
-        const int pi = (int)(g - (long long)n * pix_per_img);
-        int l = 0;
-        while (l + 1 < a.nl && pi >= a.pix_off[l + 1]) ++l;
-        const int cell = pi - a.pix_off[l];
-        lv[i] = l; cellv[i] = cell; nv[i] = n;
-        hp[i] = reinterpret_cast<const T*>(a.head[l]) + ((long long)n * a.ny[l] * a.nx[l] + cell) * a.ld[l];
-#pragma unroll
-        for (int k = 0; k < KR; ++k) raw[i][k] = o_k[k] >= 0 ? to_f32(hp[i][k * 64 + lane]) : 0.f;
+        const int cell = wave * PPW + i;
+        live[i] = cell < a.hw;
+        const int c = live[i] ? cell : 0;
+        hp[i] = (in_ptr)(a.head) + ((long long)n * a.hw + c) * a.ld;
+        const long long orow = (long long)n * a.rows_per_img + c;
+        op[i] = (out_ptr)(a.out) + orow * no;
+        mp[i] = (out_ptr)(a.row_max) + orow;
+        // grid offsets: (col, row) of the cell, or -- "transposed" -- the np.meshgrid(arange(ny), arange(nx)) table of
+        // shape (nx, ny) re-read as (ny, nx): flat cell f holds (f / ny, f % ny), which is (row, col) on square maps.
+        const int d = a.transposed ? a.ny : a.nx;
+        const int q = div_small(c, d, a.rd);
+        const int rem = c - q * d;
+        const float gx = a.transposed ? (float)q : (float)rem;
+        const float gy = a.transposed ? (float)rem : (float)q;
+        g_l[i] = lane == 0 ? gx : gy;
     }
 
+    auto load = [&](int i, int an, float (&raw)[OR]) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int l = lv[i];
-        if (l < 0) continue;   // wave-uniform
-        const int cell = cellv[i];
-        const int nx = a.nx[l], ny = a.ny[l];
-        const int row = cell / nx, col = cell - row * nx;
-        // "transposed": the np.meshgrid(arange(ny), arange(nx)) table of shape (nx, ny) re-read as (ny, nx):
-        // flat cell f holds (f / ny, f % ny) -- (row, col) on square maps.
-        const float gx = a.transposed ? (float)(cell / ny) : (float)col;
-        const float gy = a.transposed ? (float)(cell % ny) : (float)row;
-        const float stride = a.stride[l];
-        const long long orow0 = (long long)nv[i] * rows_per_img + a.box_off[l] + cell;   // + an*ny*nx
-        float v[KR];
+        for (int r = 0; r < OR; ++r) {
+            const int o = r * 64 + lane;
+            const bool ok = r < 2 ? col_ok[r < 2 ? r : 0] : o < no;
+            raw[r] = ok ? to_f32(hp[i][an * no + o]) : 0.f;
+        }
+    };
+    auto finish = [&](int i, int an, const float (&raw)[OR]) {
+        out_ptr ob = op[i] + (long long)an * a.hw * no;
+        float v[OR];
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            const int o = o_k[k];
-            if (o < 0) { v[k] = 0.f; continue; }
-            const int an = an_k[k];
-            const float s = sigmoidf_(raw[i][k]);
-            float val = s;
-            if (o < 2) {
-                val = (s * 2.0f - 0.5f + (o == 0 ? gx : gy)) * stride;
-            } else if (o < 4) {
-                const float t = s * 2.0f;
-                val = t * t * a.anchor[l][2 * an + (o - 2)];
-            }
-            v[k] = val;
-            a.out[(orow0 + (long long)an * ny * nx) * a.no + o] = val;
+        for (int r = 0; r < OR; ++r) v[r] = sigmoid_fast(raw[r]);
+        {   // columns 0..3 (lanes 0..3 of register 0): box centre and size
+            const float s = v[0];
+            const float t = s * 2.0f;
+            const float centre = (t - 0.5f + g_l[i]) * a.stride;
+            const float size = t * t * a.anchor[2 * an + (lane & 1)];
+            v[0] = lane < 2 ? centre : lane < 4 ? size : s;
+        }
+#pragma unroll
+        for (int r = 0; r < OR; ++r) {
+            const int o = r * 64 + lane;
+            const bool ok = r < 2 ? col_ok[r < 2 ? r : 0] : o < no;
+            if (ok) ob[o] = v[r];
         }
         if (a.row_max) {
-            for (int an = 0; an < a.na; ++an) {
-                const int ca = an * a.no + 4;
-                float t = 0.f;
+            const float obj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0]), 4));
+            float m = lane >= 5 && col_ok[0] ? v[0] * obj : -INFINITY;
 #pragma unroll
-                for (int k = 0; k < KR; ++k) t = (ca >> 6) == k ? v[k] : t;
-                const float obj = __shfl(t, ca & 63);
-                float m = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < KR; ++k)
-                    if (an_k[k] == an && o_k[k] >= 5) m = fmaxf(m, v[k] * obj);
-#pragma unroll
-                for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
-                if (lane == 0) a.row_max[orow0 + (long long)an * ny * nx] = m;
+            for (int r = 1; r < OR; ++r) {
+                const bool ok = r < 2 ? col_ok[r < 2 ? r : 0] : r * 64 + lane < no;
+                if (ok) m = fmaxf(m, v[r] * obj);
             }
+            m = wave_max(m);
+            if (lane == 0) mp[i][(long long)an * a.hw] = m;
+        }
+    };
+
+    if (NA > 0) {
+        float raw[PPW][NAR][OR];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+#pragma unroll
+            for (int an = 0; an < NAR; ++an) load(i, an, raw[i][an]);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (!live[i]) continue;   // wave-uniform
+#pragma unroll
+            for (int an = 0; an < NAR; ++an) finish(i, an, raw[i][an]);
+        }
+    } else {
+        for (int an = 0; an < na; ++an) {
+            float raw[PPW][OR];
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) load(i, an, raw[i]);
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+                if (live[i]) finish(i, an, raw[i]);
         }
     }
 }
@@ -189,39 +235,46 @@ extern "C" int ydet_decode_v5(const ydet_v5_level* levels, int nl, int N, int na
     YDET_CHECK_ARG(levels && out, "decode_v5: null pointer");
     YDET_CHECK_ARG(nl >= 1 && nl <= kMaxLevels, "decode_v5: nl=%d (1..%d)", nl, kMaxLevels);
     YDET_CHECK_ARG(na >= 1 && na <= kMaxAnchors, "decode_v5: na=%d (1..%d)", na, kMaxAnchors);
-    YDET_CHECK_ARG(N > 0 && no >= 5, "decode_v5: N=%d no=%d", N, no);
-    YDET_CHECK_ARG((long long)na * no <= 1024, "decode_v5: na*no=%lld exceeds 1024", (long long)na * no);
+    YDET_CHECK_ARG(N > 0 && N <= 65535 && no >= 5, "decode_v5: N=%d no=%d", N, no);
+    YDET_CHECK_ARG(no <= 1024, "decode_v5: no=%d exceeds 1024", no);
     YDET_CHECK_ARG(dtype_ok(head_dtype), "decode_v5: bad dtype");
-    V5Args a;
-    a.nl = nl; a.N = N; a.na = na; a.no = no; a.transposed = grid_transposed ? 1 : 0; a.out = out; a.row_max = row_max;
-    long long off = 0, pix = 0;
+    long long rows = 0;
     for (int l = 0; l < nl; ++l) {
         const ydet_v5_level& L = levels[l];
         YDET_CHECK_ARG(L.head && L.ny > 0 && L.nx > 0 && L.ld >= na * no, "decode_v5: level %d shape", l);
-        a.head[l] = (const char*)L.head; a.ny[l] = L.ny; a.nx[l] = L.nx; a.ld[l] = L.ld; a.stride[l] = L.stride;
-        for (int i = 0; i < 2 * kMaxAnchors; ++i) a.anchor[l][i] = i < 2 * na ? L.anchor_wh[i] : 0.f;
-        a.box_off[l] = (int)off;
-        a.pix_off[l] = (int)pix;
-        off += (long long)na * L.ny * L.nx;
-        pix += (long long)L.ny * L.nx;
-        YDET_CHECK_ARG(off < (1LL << 30), "decode_v5: too many boxes per image");
+        YDET_CHECK_ARG((long long)L.ny * L.nx < (1 << 22), "decode_v5: level %d has too many cells", l);
+        rows += (long long)na * L.ny * L.nx;
+        YDET_CHECK_ARG(rows < (1LL << 30), "decode_v5: too many boxes per image");
     }
-    for (int l = nl; l <= kMaxLevels; ++l) { a.box_off[l] = (int)off; a.pix_off[l] = (int)pix; }
-    a.total_pix = (long long)N * pix;
-    const bool small = na * no <= 256;
-    const int ppw = small ? 4 : 1;
-    const long long waves = (a.total_pix + ppw - 1) / ppw;
-    const long long grid = (waves + 3) / 4;
-    YDET_CHECK_ARG(grid > 0 && grid < 0x7fffffffLL, "decode_v5: grid");
     hipStream_t s = as_stream(stream);
-    if (head_dtype == YDET_BF16) {
-        if (small) hipLaunchKernelGGL((decode_v5_kernel<__bf16, 4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((decode_v5_kernel<__bf16, 16, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    } else {
-        if (small) hipLaunchKernelGGL((decode_v5_kernel<float, 4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((decode_v5_kernel<float, 16, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    long long off = 0;
+    for (int l = 0; l < nl; ++l) {
+        const ydet_v5_level& L = levels[l];
+        V5LevelArgs a;
+        a.head = (const char*)L.head;
+        a.out = out + off * no;
+        a.row_max = row_max ? row_max + off : nullptr;
+        a.ny = L.ny; a.nx = L.nx; a.ld = L.ld; a.hw = L.ny * L.nx;
+        a.na = na; a.no = no; a.transposed = grid_transposed ? 1 : 0;
+        a.rows_per_img = rows;
+        a.stride = L.stride;
+        a.rd = 1.0f / (float)(a.transposed ? L.ny : L.nx);
+        for (int i = 0; i < 2 * kMaxAnchors; ++i) a.anchor[i] = i < 2 * na ? L.anchor_wh[i] : 0.f;
+        off += (long long)na * a.hw;
+        const bool small = no <= 128;
+        const int ppw = small ? 4 : 1;
+        const dim3 grid((unsigned)((a.hw + 4 * ppw - 1) / (4 * ppw)), (unsigned)N);
+        if (head_dtype == YDET_BF16) {
+            if (small && na == 3) hipLaunchKernelGGL((decode_v5_kernel<__bf16, 2, 4, 3>), grid, dim3(256), 0, s, a);
+            else if (small) hipLaunchKernelGGL((decode_v5_kernel<__bf16, 2, 4, 0>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((decode_v5_kernel<__bf16, 16, 1, 0>), grid, dim3(256), 0, s, a);
+        } else {
+            if (small && na == 3) hipLaunchKernelGGL((decode_v5_kernel<float, 2, 4, 3>), grid, dim3(256), 0, s, a);
+            else if (small) hipLaunchKernelGGL((decode_v5_kernel<float, 2, 4, 0>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((decode_v5_kernel<float, 16, 1, 0>), grid, dim3(256), 0, s, a);
+        }
+        YDET_CHECK_LAUNCH("decode_v5_kernel");
     }
-    YDET_CHECK_LAUNCH("decode_v5_kernel");
     return YDET_OK;
 }
 
