@@ -71,18 +71,17 @@ class PackedConv:
         self.cin_real = cin_real or Cin
 
 
-def pack_conv(conv, bn=None, bn_slice=None, cin_phys=None, dtype=_ffi.BF16, device=None):
-    """Fold `bn` (optionally the channel range `bn_slice` of a wider BatchNorm) into `conv` and pack.
-
-    y = gamma * (conv(x) + bias - mean) / sqrt(var + eps) + beta, as nn.BatchNorm2d in eval mode.
-    """
+def fold_conv(conv, bn=None, bn_slice=None, device=None):
+    """(w [Cout, KH, KW, Cin] fp32, b [Cout] fp32) of `conv` with `bn` (optionally the channel range `bn_slice` of a
+    wider BatchNorm) folded in: y = gamma * (conv(x) + bias - mean) / sqrt(var + eps) + beta, as nn.BatchNorm2d
+    computes in eval mode."""
     if conv.groups != 1 or tuple(conv.dilation) != (1, 1):
         raise NotImplementedError("grouped / dilated convolutions are outside the accelerated path")
     if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
         raise NotImplementedError("only square kernels / strides / paddings are used by the reference models")
     device = device or conv.weight.device
     w = conv.weight.detach().to(device=device, dtype=torch.float32)
-    Cout, Cin, KH, KW = w.shape
+    Cout = w.shape[0]
     b = conv.bias.detach().to(device=device, dtype=torch.float32) if conv.bias is not None else torch.zeros(Cout, device=device)
     if bn is not None:
         sl = slice(*bn_slice) if bn_slice is not None else slice(None)
@@ -93,21 +92,32 @@ def pack_conv(conv, bn=None, bn_slice=None, cin_phys=None, dtype=_ffi.BF16, devi
         scale = g / torch.sqrt(var + bn.eps)
         w = w * scale.view(-1, 1, 1, 1)
         b = (b - mean) * scale + beta
+    return w.permute(0, 2, 3, 1), b
+
+
+def pack_folded(w, b, cin_phys=None, dtype=_ffi.BF16):
+    """Pack folded weights [Cout, KH, KW, Cin] + bias into the kernel's [cout_pad][kp] layout."""
+    Cout, KH, KW, Cin = w.shape
     cin_phys = cin_phys or Cin
     epc = 8 if dtype == _ffi.BF16 else 4
     if cin_phys % epc:
         raise ValueError(f"input channel count {cin_phys} must be a multiple of {epc}")
-    w = w.permute(0, 2, 3, 1)
     if cin_phys > Cin:
         w = torch.nn.functional.pad(w, (0, cin_phys - Cin))
     K = KH * KW * cin_phys
     kp = _round_up(K, 4 * epc)
     cout_pad = _round_up(Cout, 128)
-    wp = torch.zeros(cout_pad, kp, device=device, dtype=torch.float32)
+    wp = torch.zeros(cout_pad, kp, device=w.device, dtype=torch.float32)
     wp[:Cout, :K] = w.reshape(Cout, K)
-    bp = torch.zeros(cout_pad, device=device, dtype=torch.float32)
+    bp = torch.zeros(cout_pad, device=w.device, dtype=torch.float32)
     bp[:Cout] = b
     return PackedConv(wp.to(_TORCH_DT[dtype]).contiguous(), bp, cin_phys, Cout, KH, KW, kp, cout_pad, cin_real=Cin)
+
+
+def pack_conv(conv, bn=None, bn_slice=None, cin_phys=None, dtype=_ffi.BF16, device=None):
+    """Fold `bn` into `conv` and pack (see fold_conv / pack_folded)."""
+    w, b = fold_conv(conv, bn, bn_slice, device)
+    return pack_folded(w, b, cin_phys, dtype)
 
 
 class Graph:
@@ -141,6 +151,29 @@ class Graph:
         return t
 
     # ---- operators -----------------------------------------------------------------------------
+    def conv_siblings(self, x, pairs, act=_ffi.ACT_NONE, slope=0.0):
+        """Several (conv, bn) pairs that read the same input with the same geometry and activation, run as ONE
+        convolution whose output channels are the pairs' outputs side by side (the input is read once).
+        Returns the list of channel slices, in order; they share one storage."""
+        folded = [fold_conv(c, b, None, self.device) for c, b in pairs]
+        first = pairs[0][0]
+        for c, _ in pairs[1:]:
+            assert (c.kernel_size, c.stride, c.padding, c.in_channels) == (first.kernel_size, first.stride, first.padding,
+                                                                        first.in_channels), "sibling convs differ"
+        pc = pack_folded(torch.cat([w for w, _ in folded], 0), torch.cat([b for _, b in folded], 0), cin_phys=x.C, dtype=self.dt)
+        self.keep.append(pc)
+        s, p = first.stride[0], first.padding[0]
+        Ho = (x.H + 2 * p - pc.KH) // s + 1
+        Wo = (x.W + 2 * p - pc.KW) // s + 1
+        out = self.new(x.N, Ho, Wo, pc.Cout)
+        self.ops.append(("conv", dict(x=x, y=out, res=None, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
+                                      res_mode=_ffi.RES_NONE, post=None)))
+        parts, off = [], 0
+        for w, _ in folded:
+            parts.append(T(out.st, off, w.shape[0]))
+            off += w.shape[0]
+        return out, parts
+
     def conv(self, x, conv, bn=None, bn_slice=None, act=_ffi.ACT_NONE, slope=0.0, res=None,
              res_mode=_ffi.RES_NONE, out=None, out_dtype=None, external=False, post=None):
         """post = (bn, channel range or None, act, slope): a second BatchNorm + activation applied to the

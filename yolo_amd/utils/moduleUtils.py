@@ -94,11 +94,11 @@ class CSPResBlock(nn.Module):
     def forward(self, x):
         return self.act(x + self.conv2(self.conv1(x)))
 
-    def lower(self, g, x):
+    def lower(self, g, x, out=None):
         act, slope = activation_code(self.act)
         c2 = self.conv2.conv
         return g.conv(self.conv1.lower(g, x), c2[0], c2[1], act=act, slope=slope, res=x,
-                      res_mode=_ffi.RES_BEFORE_ACT)
+                      res_mode=_ffi.RES_BEFORE_ACT, out=out)
 
 
 class CSPStage(nn.Module):
@@ -116,6 +116,16 @@ class CSPStage(nn.Module):
         return self.conv3(torch.cat([self.conv1(x), self.resblock(self.conv2(x))], dim=1))
 
     def lower(self, g, x):
+        h = self.conv1.conv[0].out_channels
+        if h % g.vec == 0 and all(b.conv2.conv[0].out_channels == h for b in self.resblock):
+            # conv1 and conv2 read the same input: one convolution writes [conv1(x) | conv2(x)] into the concat
+            # buffer and the residual blocks update the second half in place
+            act, slope = activation_code(self.conv1.conv[2])
+            cat, (_, y2) = g.conv_siblings(x, [(self.conv1.conv[0], self.conv1.conv[1]),
+                                               (self.conv2.conv[0], self.conv2.conv[1])], act, slope)
+            for blk in self.resblock:
+                blk.lower(g, y2, out=y2)
+            return self.conv3.lower(g, cat)
         y1 = self.conv1.lower(g, x)
         y2 = self.conv2.lower(g, x)
         for blk in self.resblock:

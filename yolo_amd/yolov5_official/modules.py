@@ -129,6 +129,16 @@ class C3(nn.Module):
         return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), dim=1))
 
     def lower(self, g, x):
+        c_ = self.cv1.conv.out_channels
+        a1, a2 = activation_code(self.cv1.act), activation_code(self.cv2.act)
+        if a1 == a2 and c_ % g.vec == 0 and all(isinstance(b, Bottleneck) and b.cv2.conv.out_channels == c_ for b in self.m):
+            # cv1 and cv2 read the same input: one convolution writes [cv1(x) | cv2(x)] straight into the concat buffer;
+            # the bottleneck chain then updates the first half in place (its residual is read by the thread that
+            # overwrites it), so the concat never exists as an operation.
+            cat, (y, _) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1)
+            for b in self.m:
+                b.lower(g, y, out=y)
+            return self.cv3.lower(g, cat)
         y1 = _lower_chain(g, self.m, self.cv1.lower(g, x))
         y2 = self.cv2.lower(g, x)
         return self.cv3.lower(g, g.cat([y1, y2]))
