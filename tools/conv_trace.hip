@@ -1,0 +1,54 @@
+// Stand-alone timing trace of conv_dma_kernel (debugging aid, not part of libydet.so):
+//   hipcc --offload-arch=gfx950 -O3 -Iinclude -Iyolo_amd/csrc tools/conv_trace.hip -o build/conv_trace
+//   build/conv_trace N H W Cin Cout k stride
+// Prints, for a few workgroups, the cycle stamps relative to the earliest workgroup start.
+#define YDET_TRACE 1
+#include "../yolo_amd/csrc/conv.hip"
+
+#include <cstdlib>
+#include <vector>
+
+namespace ydet {
+int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n");
+    return code;
+}
+void clear_error() {}
+}  // namespace ydet
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 8) { fprintf(stderr, "usage: conv_trace N H W Cin Cout k stride\n"); return 2; }
+    const int N = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]);
+    const int k = atoi(argv[6]), st = atoi(argv[7]);
+    const int pad = k / 2, Ho = (H + 2 * pad - k) / st + 1, Wo = (W + 2 * pad - k) / st + 1;
+    const int kp = (k * k * Cin + 31) / 32 * 32, cout_pad = (Cout + 127) / 128 * 128;
+    void *x, *w, *y; float* b;
+    const size_t xb = (size_t)N * H * W * Cin * 2, wb = (size_t)cout_pad * kp * 2, yb = (size_t)N * Ho * Wo * Cout * 2;
+    CK(hipMalloc(&x, xb)); CK(hipMalloc(&w, wb)); CK(hipMalloc(&y, yb)); CK(hipMalloc((void**)&b, cout_pad * 4));
+    CK(hipMemset(x, 0x11, xb)); CK(hipMemset(w, 0x11, wb)); CK(hipMemset(b, 0, cout_pad * 4));
+    ydet_conv_desc d = {};
+    d.x = x; d.w = w; d.bias = b; d.y = y;
+    d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.KH = d.KW = k; d.stride = st; d.pad = pad; d.Ho = Ho; d.Wo = Wo;
+    d.x_ld = Cin; d.y_ld = Cout; d.kp = kp; d.cout_pad = cout_pad; d.act = YDET_ACT_SILU; d.in_dtype = d.out_dtype = YDET_BF16;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) if (ydet_launch_conv(&d, 0)) return 1;
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    const int reps = 20;
+    for (int i = 0; i < reps; ++i) ydet_launch_conv(&d, 0);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("avg %.2f us per launch (%d back to back)\n", ms * 1e3 / reps, reps);
+    std::vector<unsigned long long> t(64 * 32);
+    CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_trace), t.size() * 8));
+    unsigned long long t0 = ~0ull;
+    for (int blk = 0; blk < 64; ++blk) if (t[blk * 32] && t[blk * 32] < t0) t0 = t[blk * 32];
+    for (int blk : {0, 1, 8, 63}) {
+        printf("wg %2d:", blk);
+        for (int s = 0; s < 32; ++s) if (t[blk * 32 + s]) printf(" [%d]%llu", s, t[blk * 32 + s] - t0);
+        printf("\n");
+    }
+    return 0;
+}

@@ -28,6 +28,8 @@
 //                       contiguous channel run.
 //   conv_generic_kernel any Cin that is a multiple of the chunk: per-thread tap tracking, global ->
 //                       registers -> LDS, two stages.
+#include <type_traits>
+
 #include "ydet_internal.h"
 
 using namespace ydet;
@@ -85,32 +87,53 @@ __device__ __forceinline__ f32x4 mma(const f32x4& a, const f32x4& b, f32x4 c) {
 
 __device__ __forceinline__ float activate(float v, int act, float slope) {
     if (act == YDET_ACT_LEAKY) return v > 0.f ? v : v * slope;
-    if (act == YDET_ACT_SILU) return v / (1.0f + __expf(-v));
+    if (act == YDET_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
     return v;
 }
 
-// Four consecutive output channels co..co+3 of one pixel: bias, residual (either order), activation, and the
-// optional second affine + activation (a BatchNorm + activation that follows a concatenation).
-__device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], int co, const ConvArgs& a) {
-    if (a.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+// Four consecutive output channels of one pixel: bias, residual (either order), activation, and the optional second
+// affine + activation (a BatchNorm + activation that follows a concatenation).  MODE is fixed per launch and resolved
+// once per kernel (bit 0: SiLU, else leaky with a.slope -- slope 1 is "no activation"; bit 1: second stage present),
+// so the 64 values a lane finishes run through straight-line code.  b4 / ps4 / pb4 point at the four channels' bias,
+// post-scale and post-shift (global memory or the tile's LDS copy).
+template <int MODE>
+__device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], const float* b4, const float* ps4,
+                                        const float* pb4, const ConvArgs& a) {
+    if (b4) {
+        const float4 b = *reinterpret_cast<const float4*>(b4);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (a.res_mode == YDET_RES_BEFORE_ACT) {
+    const bool before = a.res_mode == YDET_RES_BEFORE_ACT;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = activate(v[e] + r[e], a.act, a.slope);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = activate(v[e], a.act, a.slope) + r[e];
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] + (before ? r[e] : 0.f);
+        if (MODE & 1) {
+            // x * sigmoid(x) on the hardware exp2 / reciprocal units (relative error ~1e-6, far inside the bf16 / 1e-3
+            // bars): 5 instructions instead of ~25 with an IEEE division
+            x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+        } else {
+            x = x > 0.f ? x : x * a.slope;
+        }
+        v[e] = x + (before ? 0.f : r[e]);
     }
-    if (a.post_scale) {
-        const float4 ps = *reinterpret_cast<const float4*>(a.post_scale + co);
-        const float4 pb = *reinterpret_cast<const float4*>(a.post_shift + co);
+    if (MODE & 2) {
+        const float4 ps = *reinterpret_cast<const float4*>(ps4);
+        const float4 pb = *reinterpret_cast<const float4*>(pb4);
         v[0] = activate(v[0] * ps.x + pb.x, a.post_act, a.post_slope);
         v[1] = activate(v[1] * ps.y + pb.y, a.post_act, a.post_slope);
         v[2] = activate(v[2] * ps.z + pb.z, a.post_act, a.post_slope);
         v[3] = activate(v[3] * ps.w + pb.w, a.post_act, a.post_slope);
     }
+}
+
+// Calls f(std::integral_constant<int, MODE>) for the launch's epilogue mode.
+template <typename F>
+__device__ __forceinline__ void with_epilogue_mode(const ConvArgs& a, F f) {
+    const int mode = (a.act == YDET_ACT_SILU ? 1 : 0) | (a.post_scale ? 2 : 0);
+    if (mode == 0) f(std::integral_constant<int, 0>{});
+    else if (mode == 1) f(std::integral_constant<int, 1>{});
+    else if (mode == 2) f(std::integral_constant<int, 2>{});
+    else f(std::integral_constant<int, 3>{});
 }
 
 template <typename T>
@@ -277,38 +300,55 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(const ConvArgs a) {
 
     // ---- epilogue: bias, activation, residual, store -----------------------------------------------
     const int q = lane >> 4, px = lane & 15;
+    with_epilogue_mode(a, [&](auto mode) {
+        constexpr int MODE = decltype(mode)::value;
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const long long m = m0 + wm * WM + j * 16 + px;
-        if (m >= a.M) continue;
-        char* yrow = a.y + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
-        const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
+        for (int j = 0; j < FM; ++j) {
+            const long long m = m0 + wm * WM + j * 16 + px;
+            if (m >= a.M) continue;
+            char* yrow = a.y + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
+            const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int co = n0 + wn * WN + i * 16 + q * 4;
-            if (co >= a.Cout) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            float r[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.vec_store) {
-                if (rrow) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
-                finish4(v, r, co, a);
-                store4<TOUT>(yrow + (size_t)co * sizeof(TOUT), v);
-            } else {
+            for (int i = 0; i < FN; ++i) {
+                const int co = n0 + wn * WN + i * 16 + q * 4;
+                if (co >= a.Cout) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* b4 = a.bias ? a.bias + co : nullptr;
+                if (a.vec_store) {
+                    if (rrow) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
+                    finish4<MODE>(v, r, b4, a.post_scale + co, a.post_shift + co, a);
+                    store4<TOUT>(yrow + (size_t)co * sizeof(TOUT), v);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
-                finish4(v, r, co, a);
+                    for (int e = 0; e < 4; ++e)
+                        if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
+                    finish4<MODE>(v, r, b4, a.post_scale + co, a.post_shift + co, a);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
+                }
             }
         }
-    }
+    });
 }
 
 
 // 16 zero bytes every padded tap is loaded from (LDS-DMA cannot predicate a lane to zero).
 __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+// Debugging aid (tools/conv_trace.hip builds this file with -DYDET_TRACE): cycle stamps of wave 0 of the first
+// 64 workgroups at up to 32 points of conv_dma_kernel.
+#ifdef YDET_TRACE
+__device__ unsigned long long g_trace[64 * 32];
+#define YDET_STAMP(slot)                                                                      \
+    do {                                                                                      \
+        if (blockIdx.x < 64 && threadIdx.x == 0 && (slot) < 32)                               \
+            g_trace[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter();                 \
+    } while (0)
+#else
+#define YDET_STAMP(slot) do { } while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -338,12 +378,24 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WARPS_N, wm = wave / WARPS_N;
+    YDET_STAMP(0);
 
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = bid % a.tiles_n;
     const long long tile_m = bid / a.tiles_n;
     const int n0 = tile_n * BN;
     const long long m0 = tile_m * BM;
+
+    // per-channel epilogue constants of this tile, parked behind the ring: visible after the first barrier of the
+    // K loop, read after the last (a global load per use would put its latency into every epilogue iteration)
+    float* cst = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
+    if (tid < BN) {
+        cst[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+        if (a.post_scale) {
+            cst[BN + tid] = a.post_scale[n0 + tid];
+            cst[2 * BN + tid] = a.post_shift[n0 + tid];
+        }
+    }
 
     // ---- staging roles ------------------------------------------------------------------------------
     // wave-instruction j of a wave fills LDS rows (j*4 + wave)*16 .. +15 of the weight (j < WJ) or pixel
@@ -427,13 +479,16 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     const int fr_off = (lane & 15) * 64 + (((lane >> 4) ^ chunk_swz(lane >> 2)) << 4);
 
     const int nk = a.kp / BK;
+    YDET_STAMP(1);
     issue(0);
     if (nk > 1) issue(1);
+    YDET_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most one younger tile (LPT instructions) is still in flight
         if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        YDET_STAMP(3 + kt);
         // every wave is past its reads of stage (kt-1)%3 == (kt+2)%3: refill it
         if (kt + 2 < nk) issue((kt + 2) % NSTAGE);
         const char* ws = smem + (kt % NSTAGE) * STAGE + (wn * WN) * 64 + fr_off;
@@ -450,66 +505,75 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------
+    YDET_STAMP(28);
     const int q = lane >> 4, px = lane & 15;
-    if (a.lds_epilogue) {
-        constexpr int V = 16 / (int)sizeof(TOUT);       // channels per 16-byte piece
-        constexpr int PIECES = BN / V;                  // pieces per pixel row of the tile
+    with_epilogue_mode(a, [&](auto mode) {
+        constexpr int MODE = decltype(mode)::value;
+        if (a.lds_epilogue) {
+            constexpr int V = 16 / (int)sizeof(TOUT);       // channels per 16-byte piece
+            constexpr int PIECES = BN / V;                  // pieces per pixel row of the tile
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            __builtin_amdgcn_s_barrier();               // the ring / the previous pass is no longer read
-            asm volatile("" ::: "memory");
+            for (int pass = 0; pass < NPASS; ++pass) {
+                __builtin_amdgcn_s_barrier();               // the ring / the previous pass is no longer read
+                asm volatile("" ::: "memory");
+                YDET_STAMP(20);
 #pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                const int pl = wm * WM + j * 16 + px;   // pixel inside the tile
-                if (pl / PM != pass) continue;
-                const long long m = m0 + pl;
-                const char* rrow = (a.res && m < a.M) ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
-                char* lrow = smem + (pl - pass * PM) * ROWB;
+                for (int j = 0; j < FM; ++j) {
+                    const int pl = wm * WM + j * 16 + px;   // pixel inside the tile
+                    if (pl / PM != pass) continue;
+                    const long long m = m0 + pl;
+                    const char* rrow = (a.res && m < a.M) ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
+                    char* lrow = smem + (pl - pass * PM) * ROWB;
 #pragma unroll
-                for (int i = 0; i < FN; ++i) {
-                    const int cl = wn * WN + i * 16 + q * 4;   // channel inside the tile
-                    const int co = n0 + cl;
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    float r[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
-                    finish4(v, r, co, a);
-                    store4<TOUT>(lrow + cl * sizeof(TOUT), v);
+                    for (int i = 0; i < FN; ++i) {
+                        const int cl = wn * WN + i * 16 + q * 4;   // channel inside the tile
+                        const int co = n0 + cl;
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        float r[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
+                        finish4<MODE>(v, r, cst + cl, cst + BN + cl, cst + 2 * BN + cl, a);
+                        store4<TOUT>(lrow + cl * sizeof(TOUT), v);
+                    }
+                }
+                YDET_STAMP(21);
+                __syncthreads();
+                YDET_STAMP(29);
+                for (int idx = tid; idx < PM * PIECES; idx += 256) {
+                    const int pl = idx / PIECES, piece = idx - pl * PIECES;
+                    const long long m = m0 + pass * PM + pl;
+                    const int co = n0 + piece * V;
+                    if (m < a.M && co < a.cout_store) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + pl * ROWB + piece * 16);
+                        *reinterpret_cast<u32x4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT)) = v;
+                    }
                 }
             }
-            __syncthreads();
-            for (int idx = tid; idx < PM * PIECES; idx += 256) {
-                const int pl = idx / PIECES, piece = idx - pl * PIECES;
-                const long long m = m0 + pass * PM + pl;
-                const int co = n0 + piece * V;
-                if (m < a.M && co < a.cout_store) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + pl * ROWB + piece * 16);
-                    *reinterpret_cast<u32x4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT)) = v;
-                }
+            YDET_STAMP(30);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const long long m = m0 + wm * WM + j * 16 + px;
+            if (m >= a.M) continue;
+            char* yrow = a.y + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
+            const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int cl = wn * WN + i * 16 + q * 4;
+                const int co = n0 + cl;
+                if (co >= a.Cout) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
+                finish4<MODE>(v, r, cst + cl, cst + BN + cl, cst + 2 * BN + cl, a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
             }
         }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const long long m = m0 + wm * WM + j * 16 + px;
-        if (m >= a.M) continue;
-        char* yrow = a.y + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
-        const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int co = n0 + wn * WN + i * 16 + q * 4;
-            if (co >= a.Cout) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            float r[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
-            finish4(v, r, co, a);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
-        }
-    }
+    });
 }
 
 template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
@@ -524,7 +588,7 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     // its weight image is half padding under the DMA group layout)
     if (BN >= 64 && a.Cin % BK == 0 && a.KH * a.KW <= 32) {
         constexpr int WROWS = BN < 64 ? 64 : BN;
-        const size_t lds_dma = 3 * (size_t)(WROWS + BM) * 64;
+        const size_t lds_dma = 3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float);
         a.lds_epilogue = (a.y_ld % (16 / (int)sizeof(TOUT)) == 0 && a.y_coff % (16 / (int)sizeof(TOUT)) == 0 &&
                           a.cout_store % (16 / (int)sizeof(TOUT)) == 0)
                              ? 1
@@ -596,7 +660,8 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
     a.stride = d->stride; a.pad = d->pad; a.Ho = d->Ho; a.Wo = d->Wo;
     a.x_ld = d->x_ld; a.x_coff = d->x_coff; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
     a.res_ld = d->res_ld; a.res_coff = d->res_coff;
-    a.kp = d->kp; a.act = d->act; a.res_mode = d->res_mode; a.slope = d->slope;
+    a.kp = d->kp; a.act = d->act; a.res_mode = d->res_mode;
+    a.slope = d->act == YDET_ACT_NONE ? 1.0f : d->slope;   // the leaky form with slope 1 is the identity
     a.M = (long long)d->N * d->Ho * d->Wo;
     a.tiles_n = 0;
     a.lds_epilogue = 0;
