@@ -95,6 +95,15 @@ typedef struct {
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 
+/* Focus + the first convolution, straight from the NCHW image: yolov5_official/modules.py:285-293 (the slicing
+ * torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1) followed by Conv) when it is
+ * layer 0 of the network (yolov5_official/yamls/yolov5s.yaml backbone[0]); also the NCHW -> NHWC edge conversion.
+ * d->x is the image [N, 3, H, W] (x_dtype, contiguous, H and W even), d->H / d->W its size, d->Cin = 3; the
+ * convolution is 3x3 / stride 1 / pad 1 over the 12 focus channels, with w / bias packed as for
+ * ydet_conv2d_nhwc for 16 input channels (focus channel q*3 + c, then 4 zeros; kp = 160); d->y is the NHWC bf16
+ * slice [N, H/2, W/2, Cout], Cout <= 64.  bf16 weights / output only; x_ld, x_coff, res and post_* are unused. */
+int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Pooling / resampling / layout operators on NHWC slices.
  * ------------------------------------------------------------------------------------------ */
@@ -229,7 +238,8 @@ typedef enum {
     YDET_OP_COPY = 6,
     YDET_OP_NCHW2NHWC = 7,     /* slice: x=src NCHW, C = real channels; iarg = focus, iarg2 = c_pad,
                                   iarg3 = source dtype */
-    YDET_OP_NHWC2NCHW = 8      /* iarg3 = destination dtype */
+    YDET_OP_NHWC2NCHW = 8,     /* iarg3 = destination dtype */
+    YDET_OP_FOCUS_CONV = 9     /* conv: as ydet_focus_conv3x3_nchw; iarg3 = image dtype */
 } ydet_op_kind;
 
 typedef struct {

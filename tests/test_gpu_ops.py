@@ -374,3 +374,29 @@ def test_conv_argument_validation():
     assert rc == -1 and b"null" in lib.ydet_last_error()
     with pytest.raises(RuntimeError):
         _ffi.check(rc, "conv")
+
+
+# ---- Focus + first convolution fused with the NCHW edge -----------------------------------------------------------
+@pytest.mark.parametrize("shape,cout", [((2, 3, 64, 96), 32), ((1, 3, 50, 70), 32), ((2, 3, 32, 64), 48), ((1, 3, 16, 16), 64)])
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
+def test_focus_stem_fused(shape, cout, src):
+    """Image sizes that are not multiples of the 8 x 32 patch, 32 / 48 / 64 output channels, fp32 and bf16 images."""
+    from yolo_amd.yolov5_official.modules import Focus
+    from yolo_amd.synthetic import init_deterministic
+    m = Focus(3, cout, 3)
+    init_deterministic(m, seed=3)
+    m.eval()
+    x = torch.randn(*shape, generator=_gen(8, f"stem{shape}")).to(src)
+    with torch.no_grad():
+        ref = m(x.float())
+    m = m.to(DEV)
+    outs = {}
+    for compute in ("bf16", "fp32"):
+        g = engine.Graph(DEV, compute)
+        y = g.focus_stem(*shape, m.conv.conv, m.conv.bn, act=_ffi.ACT_SILU)
+        g.to_nchw(y, "y")
+        assert [k for k, _ in g.ops][0] == ("focus_conv" if compute == "bf16" else "nchw2nhwc")
+        outs[compute] = g.finalize().run(x.to(DEV))["y"].float().cpu()
+    assert outs["bf16"].shape == ref.shape
+    assert rel_err(outs["fp32"], ref) < (1e-3 if src == torch.float32 else 1e-2)
+    assert rel_err(outs["bf16"], ref) < 2e-2

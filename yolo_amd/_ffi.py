@@ -13,7 +13,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
- OP_NHWC2NCHW) = range(9)
+ OP_NHWC2NCHW, OP_FOCUS_CONV) = range(10)
 MAX_ANCHORS = 8
 ABI_VERSION = 3   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
@@ -70,6 +70,7 @@ SYMBOLS = {
     "ydet_last_error": (C.c_char_p, []),
     "ydet_abi_version": (C.c_int, []),
     "ydet_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ydet_focus_conv3x3_nchw": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_maxpool2x2_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
     "ydet_maxpool2x2s1_zeropad_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
     "ydet_spp_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),

@@ -28,6 +28,8 @@
 //                       contiguous channel run.
 //   conv_generic_kernel any Cin that is a multiple of the chunk: per-thread tap tracking, global ->
 //                       registers -> LDS, two stages.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "ydet_internal.h"
@@ -612,6 +614,17 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
 
 template <typename TIN, typename TOUT>
 int launch_dtype(const ConvArgs& a, hipStream_t stream) {
+    // YDET_CONV_TILE=<channels>x<pixels> forces a tile shape (tuning aid)
+    static const char* forced = getenv("YDET_CONV_TILE");
+    if (forced) {
+        int bn = 0, bm = 0;
+        if (sscanf(forced, "%dx%d", &bn, &bm) == 2) {
+            if (bn == 32 && bm == 256) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
+            if (bn == 64 && bm == 128) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
+            if (bn == 128 && bm == 128) return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
+            if (bn == 128 && bm == 64) return launch_tile<TIN, TOUT, 128, 64, 2, 2>(a, stream);
+        }
+    }
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
     if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
     return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);

@@ -98,6 +98,7 @@ static int run_ops_impl(const ydet_op* ops, int n_ops, hipStream_t s, ydet_timer
         int rc;
         switch (op.kind) {
             case YDET_OP_CONV: rc = ydet_launch_conv(&op.conv, s); break;
+            case YDET_OP_FOCUS_CONV: rc = ydet_launch_focus_conv(&op.conv, op.iarg3, s); break;
             case YDET_OP_MAXPOOL2:
             case YDET_OP_MAXPOOL2S1:
             case YDET_OP_SPP:

@@ -1,0 +1,195 @@
+// First layer of the YOLOv5 networks in one pass over the NCHW image (gfx950): Focus slicing (space to depth by 2,
+// channel order (dy,dx) = (0,0),(1,0),(0,1),(1,1)) + 3x3 convolution + folded BatchNorm + activation, bf16 MFMA with
+// fp32 accumulation, NHWC bf16 output.  The image is read once in its native layout and the 12-channel focus tensor
+// never exists in memory.
+//
+// A workgroup produces an 8 x 32 patch of output pixels.  It gathers the 20 x 68 x 3 image patch underneath into an
+// LDS tile laid out like the focus tensor, F[10][34][16] bf16 (12 channels + 4 zeros per pixel, 32 bytes), so the
+// im2col operand of an MFMA K-step (2 filter taps x 16 channels) is one 16-byte LDS read per lane.  The packed
+// weights (k = tap*16 + channel, 5 K-steps) stay in registers for the whole kernel.
+#include <type_traits>
+
+#include "ydet_internal.h"
+
+using namespace ydet;
+
+namespace {
+
+constexpr int TH = 8, TW = 32;            // output pixels per workgroup
+constexpr int FH = TH + 2, FW = TW + 2;   // focus pixels underneath (3x3, pad 1)
+constexpr int KSTEPS = 5;                 // 9 taps x 16 channels = 144 -> 160 = 5 x 32
+
+struct StemArgs {
+    const char* x;      // [N][3][H][W]
+    const char* w;      // packed [cout_pad][160] bf16
+    const float* bias;
+    char* y;            // NHWC bf16
+    int N, H, W, Ho, Wo, Cout, y_ld, y_coff;
+    int tiles_x, tiles_y;
+    int act;
+    float slope;
+};
+
+template <typename TX>
+struct Pair;   // two horizontally adjacent pixels of the image
+template <>
+struct Pair<float> {
+    typedef float2 type;
+    static __device__ __forceinline__ void split(const float2& v, float& a, float& b) { a = v.x; b = v.y; }
+};
+template <>
+struct Pair<__bf16> {
+    typedef unsigned int type;
+    static __device__ __forceinline__ void split(const unsigned int& v, float& a, float& b) {
+        a = __uint_as_float(v << 16);
+        b = __uint_as_float(v & 0xffff0000u);
+    }
+};
+
+template <typename TX, int FN>
+__global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 F[FH * FW * 16];
+    typedef typename Pair<TX>::type pair_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x, n = blockIdx.y;
+    const int i0 = ty * TH, j0 = tx * TW;      // first output pixel of the patch
+    const int y0 = 2 * (i0 - 1), x0 = 2 * (j0 - 1);   // first image pixel underneath
+
+    // ---- weights -> registers: lane (row = lane&15, g = lane>>4) holds k = 32 s + 8 g .. + 7 of output channel 16 i + row
+    bf16x8 wf[FN][KSTEPS];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)(i * 16 + (lane & 15)) * (KSTEPS * 32) + s * 32 + (lane >> 4) * 8) * 2);
+
+    // ---- image patch -> LDS focus tile ----------------------------------------------------------------
+    constexpr int NPAIR = 3 * (2 * FH) * FW;            // 2040 pairs: (channel, image row, focus column)
+    constexpr int PER_THREAD = (NPAIR + 255) / 256;
+    pair_t px[PER_THREAD];
+    bool ok[PER_THREAD];
+    const TX* img = reinterpret_cast<const TX*>(a.x) + (size_t)n * 3 * a.H * a.W;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int idx = tid + 256 * k;
+        const int c = idx / (2 * FH * FW), rem = idx - c * (2 * FH * FW);
+        const int ry = rem / FW, fx = rem - ry * FW;
+        const int Y = y0 + ry, X = x0 + 2 * fx;
+        ok[k] = idx < NPAIR && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+        px[k] = pair_t();
+        if (ok[k]) px[k] = *reinterpret_cast<const pair_t*>(img + ((size_t)c * a.H + Y) * a.W + X);
+    }
+    for (int p = tid; p < FH * FW; p += 256)            // channels 12..15 of every focus pixel
+        *reinterpret_cast<unsigned long long*>(F + p * 16 + 12) = 0ull;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx >= NPAIR) continue;
+        const int c = idx / (2 * FH * FW), rem = idx - c * (2 * FH * FW);
+        const int ry = rem / FW, fx = rem - ry * FW;
+        float v0, v1;
+        Pair<TX>::split(px[k], v0, v1);
+        __bf16* f = F + ((ry >> 1) * FW + fx) * 16;
+        const int dy = ry & 1;
+        f[dy * 3 + c] = (__bf16)v0;          // (dy, dx = 0)
+        f[(2 + dy) * 3 + c] = (__bf16)v1;    // (dy, dx = 1)
+    }
+    __syncthreads();
+
+    // ---- MFMA: wave w owns output rows 2w, 2w+1; pixel group j = row (j>>1), columns 16 (j&1) .. + 15 ----------
+    f32x4 acc[FN][4];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int p = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        const int tap = 2 * s + (g >> 1);           // K-step s covers taps 2s and 2s+1; tap 9 is padding
+        const int kh = tap / 3, kw = tap - kh * 3;
+        bf16x8 xf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 2 * wave + (j >> 1), c = 16 * (j & 1) + p;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(F + (((r + (tap < 9 ? kh : 0)) * FW + c + (tap < 9 ? kw : 0)) * 16 + (g & 1) * 8));
+            xf[j] = tap < 9 ? v : bf16x8{};
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][s], xf[j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane holds channels 16 i + 4 g .. + 3 of pixel p of group j ---------------------------------------
+    auto finish = [&](auto silu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oi = i0 + 2 * wave + (j >> 1), oj = j0 + 16 * (j & 1) + p;
+            if (oi >= a.Ho || oj >= a.Wo) continue;
+            char* yrow = a.y + ((((size_t)n * a.Ho + oi) * a.Wo + oj) * a.y_ld + a.y_coff) * 2;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int co = i * 16 + g * 4;
+                if (co >= a.Cout) continue;
+                const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e];
+                    if (decltype(silu)::value)
+                        x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+                    else
+                        x = x > 0.f ? x : x * a.slope;
+                    o[e] = (__bf16)x;
+                }
+                *reinterpret_cast<bf16x4*>(yrow + co * 2) = o;
+            }
+        }
+    };
+    if (a.act == YDET_ACT_SILU) finish(std::true_type{});
+    else finish(std::false_type{});
+}
+
+}  // namespace
+
+int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {
+    YDET_CHECK_ARG(d != nullptr && d->x && d->w && d->y, "focus_conv: null pointer");
+    YDET_CHECK_ARG(dtype_ok(x_dtype), "focus_conv: bad image dtype");
+    YDET_CHECK_ARG(d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "focus_conv: bf16 weights and output only");
+    YDET_CHECK_ARG(d->N > 0 && d->N <= 65535 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0,
+                   "focus_conv: image %d x %d x %d", d->N, d->H, d->W);
+    YDET_CHECK_ARG(d->Cin == 3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1,
+                   "focus_conv: 3 image channels and a 3x3 / stride 1 / pad 1 convolution only");
+    YDET_CHECK_ARG(d->Ho == d->H / 2 && d->Wo == d->W / 2, "focus_conv: output must be H/2 x W/2");
+    YDET_CHECK_ARG(d->Cout >= 1 && d->Cout <= 64 && d->Cout % 4 == 0 && d->cout_pad >= 64, "focus_conv: Cout=%d (multiple of 4, <= 64)", d->Cout);
+    YDET_CHECK_ARG(d->kp == KSTEPS * 32, "focus_conv: weights must be packed for 16 input channels (kp = %d)", KSTEPS * 32);
+    YDET_CHECK_ARG(d->y_ld % 4 == 0 && d->y_coff % 4 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld,
+                   "focus_conv: output slice");
+    YDET_CHECK_ARG(d->res == nullptr && d->post_scale == nullptr, "focus_conv: no residual / second stage");
+    YDET_CHECK_ARG(((uintptr_t)d->x & 7) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 7) == 0 &&
+                       ((uintptr_t)d->bias & 15) == 0, "focus_conv: pointer alignment");
+    StemArgs a;
+    a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
+    a.tiles_x = (a.Wo + TW - 1) / TW; a.tiles_y = (a.Ho + TH - 1) / TH;
+    a.act = d->act;
+    a.slope = d->act == YDET_ACT_NONE ? 1.0f : d->slope;
+    const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)a.N);
+    const bool wide = d->Cout > 32;
+    if (x_dtype == YDET_F32) {
+        if (wide) hipLaunchKernelGGL((focus_conv3x3_kernel<float, 4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((focus_conv3x3_kernel<float, 2>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (wide) hipLaunchKernelGGL((focus_conv3x3_kernel<__bf16, 4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((focus_conv3x3_kernel<__bf16, 2>), grid, dim3(256), 0, stream, a);
+    }
+    YDET_CHECK_LAUNCH("focus_conv3x3_kernel");
+    return YDET_OK;
+}
+
+extern "C" int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream) {
+    clear_error();
+    return ydet_launch_focus_conv(d, x_dtype, as_stream(stream));
+}

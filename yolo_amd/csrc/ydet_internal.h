@@ -55,3 +55,4 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 // Internal launchers shared by the public entry points and ydet_run_ops.
 int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream);
+int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream);

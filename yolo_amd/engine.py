@@ -150,6 +150,23 @@ class Graph:
         t.focused = bool(focus)
         return t
 
+    def focus_stem(self, N, Cch, H, W, conv, bn=None, act=_ffi.ACT_NONE, slope=0.0, src_dtype=_ffi.F32):
+        """API edge + first layer: NCHW image -> Focus slicing -> 3x3 convolution (+ BatchNorm + activation) -> NHWC.
+        One fused kernel on the bf16 path when the convolution qualifies (3 image channels, 3x3 / stride 1 / pad 1,
+        at most 64 output channels); otherwise the layout kernel (with the slicing folded in) followed by a
+        regular convolution."""
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        fused = (self.dt == _ffi.BF16 and Cch == 3 and (k, s, p) == (3, 1, 1) and conv.groups == 1 and H % 2 == 0
+                 and W % 2 == 0 and conv.out_channels <= 64 and conv.out_channels % 4 == 0)
+        if not fused:
+            return self.conv(self.input_nchw(N, Cch, H, W, focus=True, src_dtype=src_dtype), conv, bn, act=act, slope=slope)
+        pc = pack_conv(conv, bn, None, cin_phys=16, dtype=self.dt, device=self.device)
+        self.keep.append(pc)
+        out = self.new(N, H // 2, W // 2, pc.Cout)
+        self.ops.append(("focus_conv", dict(y=out, pc=pc, N=N, C=Cch, H=H, W=W, act=act, slope=float(slope), src_dtype=src_dtype)))
+        self.ext_in.append(len(self.ops) - 1)
+        return out
+
     # ---- operators -----------------------------------------------------------------------------
     def conv_siblings(self, x, pairs, act=_ffi.ACT_NONE, slope=0.0):
         """Several (conv, bn) pairs that read the same input with the same geometry and activation, run as ONE
@@ -285,6 +302,17 @@ class Plan:
             self.op_info.append(_op_info(kind, a))
             if kind == "conv":
                 self._fill_conv(i, op, a)
+            elif kind == "focus_conv":
+                op.kind = _ffi.OP_FOCUS_CONV
+                d, pc = op.conv, a["pc"]
+                root, off = a["y"].resolve()
+                d.y, d.w, d.bias = root.tensor.data_ptr(), pc.w.data_ptr(), pc.b.data_ptr()
+                d.N, d.H, d.W, d.Cin = a["N"], a["H"], a["W"], a["C"]
+                d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, 3, 3, 1, 1
+                d.Ho, d.Wo = a["H"] // 2, a["W"] // 2
+                d.y_ld, d.y_coff, d.kp, d.cout_pad = root.ld, off, pc.kp, pc.cout_pad
+                d.act, d.slope, d.in_dtype, d.out_dtype = a["act"], a["slope"], _ffi.BF16, root.dtype
+                op.iarg3 = a["src_dtype"]
             elif kind == "nchw2nhwc":
                 op.kind = _ffi.OP_NCHW2NHWC
                 root, off = a["y"].resolve()
@@ -368,9 +396,14 @@ class Plan:
             x = x.contiguous()
             held.append(x)
             op = self.ops[i]
-            assert tuple(x.shape) == (op.slice.N, op.slice.C, op.slice.H, op.slice.W), \
-                f"plan built for {(op.slice.N, op.slice.C, op.slice.H, op.slice.W)}, got {tuple(x.shape)}"
-            op.slice.x = x.data_ptr()
+            if op.kind == _ffi.OP_FOCUS_CONV:
+                want = (op.conv.N, op.conv.Cin, op.conv.H, op.conv.W)
+                assert tuple(x.shape) == want, f"plan built for {want}, got {tuple(x.shape)}"
+                op.conv.x = x.data_ptr()
+            else:
+                want = (op.slice.N, op.slice.C, op.slice.H, op.slice.W)
+                assert tuple(x.shape) == want, f"plan built for {want}, got {tuple(x.shape)}"
+                op.slice.x = x.data_ptr()
             op.iarg3 = _ffi.BF16 if x.dtype == torch.bfloat16 else _ffi.F32
         for i, field, root in self.patch_out:
             ptr = root.tensor.data_ptr()
@@ -418,6 +451,11 @@ def _op_info(kind, a):
             nbytes += y.N * y.H * y.W * y.C * esz(x)
         return dict(kind="conv", label=f"conv_igemm<{bn}x{bm},{'1x1' if one else 'kxk'}>", flops=flops, bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
+    if kind == "focus_conv":
+        y, pc = a["y"], a["pc"]
+        return dict(kind="conv", label="focus_conv3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
+                    bytes=a["N"] * a["C"] * a["H"] * a["W"] * 4 + y.N * y.H * y.W * y.C * esz(y),
+                    shape=(a["N"], a["H"], a["W"], a["C"], pc.Cout, 3, 1))
     if kind == "nchw2nhwc":
         y = a["y"]
         n = a["N"] * a["C"] * a["H"] * a["W"]

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 import yaml
 
 from .. import _ffi, engine, ops
-from .modules import C3, SPP, Bottleneck, BottleneckCSP, Concat, Contract, Conv, DWConv, Expand, Focus
+from .modules import C3, SPP, Bottleneck, BottleneckCSP, Concat, Contract, Conv, DWConv, Expand, Focus, activation_code
 
 DEFAULT_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yamls", "yolov5s.yaml")
 
@@ -313,7 +313,8 @@ class Model(engine.AcceleratedModule):
         layers = list(self.model)
         first = layers[0]
         if isinstance(first, Focus) and first.f == -1:
-            x = first.conv.lower(g, g.input_nchw(N, C, H, W, focus=True))
+            act, slope = activation_code(first.conv.act)
+            x = g.focus_stem(N, C, H, W, first.conv.conv, getattr(first.conv, "bn", None), act=act, slope=slope)
         else:
             x = lower_layer(g, first, g.input_nchw(N, C, H, W))
         y = [x if first.i in self.save else None]
