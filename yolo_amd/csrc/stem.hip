@@ -52,17 +52,22 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
     typedef typename Pair<TX>::type pair_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x, n = blockIdx.y;
+    // consecutive patches of an image share halo pixels: keep them on one XCD (one L2)
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x, ty = bid / a.tiles_x, n = blockIdx.y;
     const int i0 = ty * TH, j0 = tx * TW;      // first output pixel of the patch
     const int y0 = 2 * (i0 - 1), x0 = 2 * (j0 - 1);   // first image pixel underneath
 
-    // ---- weights -> registers: lane (row = lane&15, g = lane>>4) holds k = 32 s + 8 g .. + 7 of output channel 16 i + row
+    // ---- weights -> registers: lane (row = lane&15, g = lane>>4) holds k = 32 s + 8 g .. + 7 of one output channel.
+    // MFMA i of a pair (i = 2h, 2h+1) takes channel 32 h + 8 (row>>2) + 4 (i&1) + (row&3) on its row, so a lane ends
+    // up with the 8 CONSECUTIVE channels 32 h + 8 g .. + 7 of its pixel and stores them as one 16-byte piece.
     bf16x8 wf[FN][KSTEPS];
+    const int wrow = 8 * ((lane & 15) >> 2) + (lane & 3);
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
-            wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)(i * 16 + (lane & 15)) * (KSTEPS * 32) + s * 32 + (lane >> 4) * 8) * 2);
+            wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)(32 * (i >> 1) + 4 * (i & 1) + wrow) * (KSTEPS * 32) + s * 32 + (lane >> 4) * 8) * 2);
 
     // ---- image patch -> LDS focus tile ----------------------------------------------------------------
     constexpr int NPAIR = 3 * (2 * FH) * FW;            // 2040 pairs: (channel, image row, focus column)
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][s], xf[j], acc[i][j], 0, 0, 0);
     }
 
-    // ---- epilogue: lane holds channels 16 i + 4 g .. + 3 of pixel p of group j ---------------------------------------
+    // ---- epilogue: lane holds channels 32 h + 8 g .. + 7 (MFMAs 2h and 2h+1) of pixel p of group j --------------------
     auto finish = [&](auto silu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -129,14 +134,21 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
             if (oi >= a.Ho || oj >= a.Wo) continue;
             char* yrow = a.y + ((((size_t)n * a.Ho + oi) * a.Wo + oj) * a.y_ld + a.y_coff) * 2;
 #pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const int co = i * 16 + g * 4;
+            for (int h = 0; h < FN / 2; ++h) {
+                const int co = 32 * h + 8 * g;
                 if (co >= a.Cout) continue;
-                const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
-                bf16x4 o;
+                float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e) { v[e] = acc[2 * h][j][e]; v[4 + e] = acc[2 * h + 1][j][e]; }
+                if (a.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+                    const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
                     float x = v[e];
                     if (decltype(silu)::value)
                         x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
@@ -144,7 +156,12 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
                         x = x > 0.f ? x : x * a.slope;
                     o[e] = (__bf16)x;
                 }
-                *reinterpret_cast<bf16x4*>(yrow + co * 2) = o;
+                if (co + 8 <= a.Cout) {
+                    *reinterpret_cast<bf16x8*>(yrow + co * 2) = o;
+                } else {   // Cout is a multiple of 4: the last piece of e.g. 44 channels is half a vector
+                    bf16x4 o4 = {o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<bf16x4*>(yrow + co * 2) = o4;
+                }
             }
         }
     };
@@ -165,10 +182,10 @@ int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t str
     YDET_CHECK_ARG(d->Ho == d->H / 2 && d->Wo == d->W / 2, "focus_conv: output must be H/2 x W/2");
     YDET_CHECK_ARG(d->Cout >= 1 && d->Cout <= 64 && d->Cout % 4 == 0 && d->cout_pad >= 64, "focus_conv: Cout=%d (multiple of 4, <= 64)", d->Cout);
     YDET_CHECK_ARG(d->kp == KSTEPS * 32, "focus_conv: weights must be packed for 16 input channels (kp = %d)", KSTEPS * 32);
-    YDET_CHECK_ARG(d->y_ld % 4 == 0 && d->y_coff % 4 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld,
-                   "focus_conv: output slice");
+    YDET_CHECK_ARG(d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld,
+                   "focus_conv: output slice (y_ld, y_coff multiples of 8)");
     YDET_CHECK_ARG(d->res == nullptr && d->post_scale == nullptr, "focus_conv: no residual / second stage");
-    YDET_CHECK_ARG(((uintptr_t)d->x & 7) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 7) == 0 &&
+    YDET_CHECK_ARG(((uintptr_t)d->x & 7) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 15) == 0 &&
                        ((uintptr_t)d->bias & 15) == 0, "focus_conv: pointer alignment");
     StemArgs a;
     a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
