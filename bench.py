@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--per-op", default=None, help="write a per-op timing table (tsv) to this path")
+    ap.add_argument("--split", type=int, default=1, choices=[1, 2, 4],
+                    help="run the forward pass as this many side-by-side launch lists over slices of the batch; with a "
+                         "split the per-kernel events are taken in a second, unsplit loop outside the timed region")
     args = ap.parse_args()
 
     import yolo_amd
@@ -60,6 +63,7 @@ def main():
     lib = _ffi.lib()
 
     engine.set_compute_dtype(args.compute)
+    engine.set_batch_split(args.split)
     model = Model()
     init_deterministic(model, seed=0, head_convs=list(model.model[-1].m))
     model = model.to(dev).eval()
@@ -89,9 +93,7 @@ def main():
         return cnt
 
     def _build(m, xx, compute):
-        g = engine.Graph(xx.device, compute)
-        m._lower(g, *xx.shape)
-        return g.finalize()
+        return engine.build_plan(xx.device, compute, xx.shape[0], lambda g, n: m._lower(g, n, *xx.shape[1:]))
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -107,12 +109,24 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        split = plan_holder["plan"].R > 1
         for k in range(args.steps):
-            step(timer, k * (n_ops + 1), evs[k])
+            if split:
+                step()
+            else:
+                step(timer, k * (n_ops + 1), evs[k])
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
+        if split:   # kernel statistics: the same steps again as ONE launch list, events after every op
+            engine.set_batch_split(1)
+            model.invalidate_plans()
+            step()
+            torch.cuda.synchronize()
+            for k in range(args.steps):
+                step(timer, k * (n_ops + 1), evs[k])
+            torch.cuda.synchronize()
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -174,7 +188,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"YOLOv5s (yolov5_official/model.py) {args.size}x{args.size}, batch {args.batch} per GPU, "
                                "forward + Detect decode + NMS (conf 0.001, iou 0.6, multi_label, max_det 300)",
-                   "images_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                   "images_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}", "batch_split": args.split,
                    "weights": "seeded synthetic (yolo_amd.synthetic.init_deterministic)"},
         "roofline": {"bound": "mfma", "kernel": dom_label, "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(dom_tf / peak, 4), "traffic": None,

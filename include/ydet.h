@@ -251,6 +251,13 @@ typedef struct {
 
 int ydet_run_ops(const ydet_op* ops /* host */, int n_ops, void* stream);
 
+/* Several independent launch lists (e.g. the same network planned for two halves of the batch) run side by side:
+ * list 0 on `stream`, the others on side streams the library keeps per device, forked after the work already queued
+ * on `stream` and joined back into it before the call returns -- to the caller it behaves like one launch on `stream`.
+ * Kernels of different lists overlap on the GPU, which fills the tails of grids that do not cover all 256 CUs.
+ * n_lists <= 4.  No counterpart in the reference (its forward pass is one Python loop on one stream). */
+int ydet_run_op_lists(const ydet_op* const* lists /* host */, const int* counts /* host */, int n_lists, void* stream);
+
 /* Measurement aid (no counterpart in the reference, which has no profiler): the same executor, but a
  * hipEvent is recorded on `stream` before the first op and after every op, into marks
  * first_mark .. first_mark + n_ops of `timer`.  Nothing synchronises; after the caller has synchronised

@@ -204,6 +204,39 @@ def test_v5s_compat_detect_golden(golden):
     assert rel_err(z.cpu().numpy(), g["z"]) < 1e-3
 
 
+def test_batch_split_matches_single_list():
+    """Two half-batch launch lists side by side (ydet_run_op_lists) give bit-identical results to one list."""
+    engine.set_compute_dtype("bf16")
+    m = build_v5s(20).to(DEV)
+    x = images(16, 96, seed=7).to(DEV)
+    try:
+        with torch.no_grad():
+            z1, xs1 = m(x)
+            engine.set_batch_split(2)
+            m.invalidate_plans()
+            z2, xs2 = m(x)
+            plan = next(iter(m._plans().plans.values()))
+            assert plan.R == 2
+            z3, _ = m(x)        # replay of the cached split plan
+    finally:
+        engine.set_batch_split(1)
+        m.invalidate_plans()
+    assert torch.equal(z1, z2) and torch.equal(z1, z3)
+    for a, b in zip(xs1, xs2):
+        assert torch.equal(a, b)
+    net = build_fa("v3tiny", 64).to(DEV)
+    xa = images(16, 64, seed=8, kind="randn").to(DEV)
+    try:
+        b1, s1 = net.decode_batch(xa)
+        engine.set_batch_split(2)
+        net.invalidate_plans()
+        b2, s2 = net.decode_batch(xa)
+    finally:
+        engine.set_batch_split(1)
+        net.invalidate_plans()
+    assert torch.equal(b1, b2) and torch.equal(s1, s2)
+
+
 def test_v5s_batch_consistency_and_replan():
     """Same image in different batch positions / batch sizes gives the same rows; reloading weights re-plans."""
     engine.set_compute_dtype("fp32")

@@ -92,6 +92,7 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ydet_box_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ydet_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
+    "ydet_run_op_lists": (C.c_int, [C.POINTER(C.POINTER(Op)), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
     "ydet_timer_create": (C.c_void_p, [C.c_int]),
     "ydet_timer_destroy": (None, [C.c_void_p]),
     "ydet_run_ops_timed": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

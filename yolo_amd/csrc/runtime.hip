@@ -1,4 +1,5 @@
 // Error reporting and the launch-list executor of libydet.so.
+#include <pthread.h>
 #include <string.h>
 
 #include <new>
@@ -89,41 +90,106 @@ extern "C" int ydet_run_ops_timed(const ydet_op* ops, int n_ops, void* stream, y
     return run_ops_impl(ops, n_ops, ydet::as_stream(stream), timer, first_mark);
 }
 
+static int launch_op(const ydet_op& op, hipStream_t s) {
+    switch (op.kind) {
+        case YDET_OP_CONV: return ydet_launch_conv(&op.conv, s);
+        case YDET_OP_FOCUS_CONV: return ydet_launch_focus_conv(&op.conv, op.iarg3, s);
+        case YDET_OP_MAXPOOL2:
+        case YDET_OP_MAXPOOL2S1:
+        case YDET_OP_SPP:
+        case YDET_OP_UPSAMPLE:
+        case YDET_OP_SPACE2DEPTH:
+        case YDET_OP_COPY: return ydet_launch_slice(op.kind, &op.slice, op.iarg, s);
+        case YDET_OP_NCHW2NHWC:
+            return ydet_launch_nchw_to_nhwc(op.slice.x, op.slice.y, op.slice.N, op.slice.C, op.slice.H, op.slice.W,
+                                            op.slice.y_ld, op.slice.y_coff, op.iarg2, op.iarg3, op.slice.dtype, op.iarg, s);
+        case YDET_OP_NHWC2NCHW:
+            return ydet_launch_nhwc_to_nchw(op.slice.x, op.slice.y, op.slice.N, op.slice.C, op.slice.H, op.slice.W,
+                                            op.slice.x_ld, op.slice.x_coff, op.slice.dtype, op.iarg3, s);
+        default: return ydet::fail(YDET_ERR_ARG, "unknown op kind %d", op.kind);
+    }
+}
+
+static int op_failed(int rc, int i, int n_ops) {
+    char msg[400];
+    strncpy(msg, ydet::g_err, sizeof(msg) - 1);
+    msg[sizeof(msg) - 1] = 0;
+    return ydet::fail(rc, "run_ops: op %d of %d: %s", i, n_ops, msg);
+}
+
 static int run_ops_impl(const ydet_op* ops, int n_ops, hipStream_t s, ydet_timer* timer, int first_mark) {
     if (n_ops < 0 || (n_ops > 0 && !ops)) return ydet::fail(YDET_ERR_ARG, "run_ops: bad op list");
     if (timer && hipEventRecord(timer->ev[first_mark], s) != hipSuccess)
         return ydet::fail(YDET_ERR_LAUNCH, "run_ops: hipEventRecord failed");
     for (int i = 0; i < n_ops; ++i) {
-        const ydet_op& op = ops[i];
-        int rc;
-        switch (op.kind) {
-            case YDET_OP_CONV: rc = ydet_launch_conv(&op.conv, s); break;
-            case YDET_OP_FOCUS_CONV: rc = ydet_launch_focus_conv(&op.conv, op.iarg3, s); break;
-            case YDET_OP_MAXPOOL2:
-            case YDET_OP_MAXPOOL2S1:
-            case YDET_OP_SPP:
-            case YDET_OP_UPSAMPLE:
-            case YDET_OP_SPACE2DEPTH:
-            case YDET_OP_COPY: rc = ydet_launch_slice(op.kind, &op.slice, op.iarg, s); break;
-            case YDET_OP_NCHW2NHWC:
-                rc = ydet_launch_nchw_to_nhwc(op.slice.x, op.slice.y, op.slice.N, op.slice.C, op.slice.H, op.slice.W,
-                                              op.slice.y_ld, op.slice.y_coff, op.iarg2, op.iarg3, op.slice.dtype,
-                                              op.iarg, s);
-                break;
-            case YDET_OP_NHWC2NCHW:
-                rc = ydet_launch_nhwc_to_nchw(op.slice.x, op.slice.y, op.slice.N, op.slice.C, op.slice.H, op.slice.W,
-                                              op.slice.x_ld, op.slice.x_coff, op.slice.dtype, op.iarg3, s);
-                break;
-            default: rc = ydet::fail(YDET_ERR_ARG, "unknown op kind %d", op.kind); break;
-        }
-        if (rc != YDET_OK) {
-            char msg[400];
-            strncpy(msg, ydet::g_err, sizeof(msg) - 1);
-            msg[sizeof(msg) - 1] = 0;
-            return ydet::fail(rc, "run_ops: op %d of %d: %s", i, n_ops, msg);
-        }
+        const int rc = launch_op(ops[i], s);
+        if (rc != YDET_OK) return op_failed(rc, i, n_ops);
         if (timer && hipEventRecord(timer->ev[first_mark + i + 1], s) != hipSuccess)
             return ydet::fail(YDET_ERR_LAUNCH, "run_ops: hipEventRecord failed");
     }
     return YDET_OK;
+}
+
+// ---- independent launch lists side by side -------------------------------------------------------------------------
+// Per device: a few non-blocking side streams and the events that fork them from / join them to the caller's
+// stream.  Created on first use, kept for the life of the process (streams and events own no device memory).
+namespace {
+constexpr int kMaxLists = 4, kMaxDevices = 64;
+struct SidePool {
+    bool ready = false;
+    hipStream_t side[kMaxLists - 1];
+    hipEvent_t fork, join[kMaxLists - 1];
+};
+SidePool g_pool[kMaxDevices];
+pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+
+SidePool* side_pool() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    pthread_mutex_lock(&g_pool_lock);
+    SidePool* p = &g_pool[dev];
+    if (!p->ready) {
+        bool ok = hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < kMaxLists - 1; ++i)
+            ok = hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming) == hipSuccess;
+        p->ready = ok;
+    }
+    pthread_mutex_unlock(&g_pool_lock);
+    return p->ready ? p : nullptr;
+}
+}  // namespace
+
+extern "C" int ydet_run_op_lists(const ydet_op* const* lists, const int* counts, int n_lists, void* stream) {
+    ydet::clear_error();
+    if (n_lists < 1 || n_lists > kMaxLists || !lists || !counts)
+        return ydet::fail(YDET_ERR_ARG, "run_op_lists: n_lists=%d (1..%d)", n_lists, kMaxLists);
+    hipStream_t main_s = ydet::as_stream(stream);
+    if (n_lists == 1) return run_ops_impl(lists[0], counts[0], main_s, nullptr, 0);
+    int longest = 0;
+    for (int r = 0; r < n_lists; ++r) {
+        if (counts[r] < 0 || (counts[r] > 0 && !lists[r])) return ydet::fail(YDET_ERR_ARG, "run_op_lists: bad list %d", r);
+        if (counts[r] > longest) longest = counts[r];
+    }
+    SidePool* pool = side_pool();
+    if (!pool) return ydet::fail(YDET_ERR_LAUNCH, "run_op_lists: could not create the side streams");
+    // fork: nothing of the side lists may start before the work already queued on the caller's stream
+    if (hipEventRecord(pool->fork, main_s) != hipSuccess) return ydet::fail(YDET_ERR_LAUNCH, "run_op_lists: fork failed");
+    for (int r = 1; r < n_lists; ++r)
+        if (hipStreamWaitEvent(pool->side[r - 1], pool->fork, 0) != hipSuccess)
+            return ydet::fail(YDET_ERR_LAUNCH, "run_op_lists: fork failed");
+    // round-robin submission keeps every queue fed
+    int rc = YDET_OK;
+    for (int i = 0; i < longest && rc == YDET_OK; ++i)
+        for (int r = 0; r < n_lists && rc == YDET_OK; ++r)
+            if (i < counts[r]) {
+                rc = launch_op(lists[r][i], r == 0 ? main_s : pool->side[r - 1]);
+                if (rc != YDET_OK) rc = op_failed(rc, i, counts[r]);
+            }
+    // join (also after a failure: the caller's stream must not run ahead of what was queued)
+    for (int r = 1; r < n_lists; ++r)
+        if (hipEventRecord(pool->join[r - 1], pool->side[r - 1]) != hipSuccess ||
+            hipStreamWaitEvent(main_s, pool->join[r - 1], 0) != hipSuccess)
+            return rc != YDET_OK ? rc : ydet::fail(YDET_ERR_LAUNCH, "run_op_lists: join failed");
+    return rc;
 }

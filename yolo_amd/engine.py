@@ -276,89 +276,107 @@ class Graph:
         self.outputs[name] = t
 
     # ---- finalize ------------------------------------------------------------------------------
-    def finalize(self):
-        return Plan(self)
+    def finalize(self, replicas=1):
+        return Plan(self, replicas)
 
 
 class Plan:
-    """Resolved launch list + the buffers it runs on."""
+    """Resolved launch list(s) + the buffers they run on.
 
-    def __init__(self, g):
+    With `replicas` R > 1 the graph describes 1/R of the batch: the plan holds R copies of the launch list, each
+    with its own activation arena, working on consecutive slices of the caller's batch (inputs and external
+    outputs are contiguous in the batch dimension, so a slice is a pointer offset).  The copies run side by side
+    (ydet_run_op_lists), which fills the GPU when single layers do not."""
+
+    def __init__(self, g, replicas=1):
         self.device = g.device
         self.g = g
-        for st in g.storages:
-            root, _ = st.root()
-            if root is st and not st.external:
-                st.tensor = torch.empty(st.N, st.H, st.W, st.ld, device=g.device, dtype=_TORCH_DT[st.dtype])
+        self.R = replicas
         n = len(g.ops)
-        self.ops = (_ffi.Op * n)()
-        self.patch_in = list(g.ext_in)  # op indices whose slice.x is a caller-supplied NCHW input
-        self.patch_out = []       # (op index, field, storage) of external NHWC outputs
-        self.nchw_out = []        # (op index, name, shape, dtype)
+        self.patch_in = list(g.ext_in)  # op indices whose source is a caller-supplied NCHW input
+        self.patch_out = []       # (op index, field, storage) of external NHWC buffers
+        self.nchw_out = []        # (op index, name, per-replica shape, dtype)
         self._ext_storages = [st for st in g.storages if st.external]
-        self.op_info = []         # per op: kind, label, algorithmic flops and bytes (measurement bookkeeping)
-        for i, (kind, a) in enumerate(g.ops):
-            op = self.ops[i]
-            self.op_info.append(_op_info(kind, a))
-            if kind == "conv":
-                self._fill_conv(i, op, a)
-            elif kind == "focus_conv":
-                op.kind = _ffi.OP_FOCUS_CONV
-                d, pc = op.conv, a["pc"]
-                root, off = a["y"].resolve()
-                d.y, d.w, d.bias = root.tensor.data_ptr(), pc.w.data_ptr(), pc.b.data_ptr()
-                d.N, d.H, d.W, d.Cin = a["N"], a["H"], a["W"], a["C"]
-                d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, 3, 3, 1, 1
-                d.Ho, d.Wo = a["H"] // 2, a["W"] // 2
-                d.y_ld, d.y_coff, d.kp, d.cout_pad = root.ld, off, pc.kp, pc.cout_pad
-                d.act, d.slope, d.in_dtype, d.out_dtype = a["act"], a["slope"], _ffi.BF16, root.dtype
-                op.iarg3 = a["src_dtype"]
-            elif kind == "nchw2nhwc":
-                op.kind = _ffi.OP_NCHW2NHWC
-                root, off = a["y"].resolve()
-                s = op.slice
-                s.y = root.tensor.data_ptr()
-                s.N, s.C, s.H, s.W = a["N"], a["C"], a["H"], a["W"]
-                s.y_ld, s.y_coff, s.dtype = root.ld, off, root.dtype
-                op.iarg, op.iarg2, op.iarg3 = a["focus"], a["c_pad"], a["src_dtype"]
-            elif kind == "nhwc2nchw":
-                op.kind = _ffi.OP_NHWC2NCHW
-                x = a["x"]
-                root, off = x.resolve()
-                s = op.slice
-                s.x = self._ptr(root, i, "x")
-                s.N, s.C, s.H, s.W = x.N, x.C, x.H, x.W
-                s.x_ld, s.x_coff, s.dtype = root.ld, off, root.dtype
-                op.iarg3 = a["dst_dtype"]
-                self.nchw_out.append((i, a["name"], (x.N, x.C, x.H, x.W), _TORCH_DT[a["dst_dtype"]]))
-            else:
-                op.kind = {"maxpool2": _ffi.OP_MAXPOOL2, "maxpool2s1": _ffi.OP_MAXPOOL2S1, "spp": _ffi.OP_SPP,
-                           "upsample": _ffi.OP_UPSAMPLE, "space2depth": _ffi.OP_SPACE2DEPTH,
-                           "copy": _ffi.OP_COPY}[kind]
-                op.iarg = a["iarg"]
-                x, y = a["x"], a["y"]
-                rx, ox = x.resolve()
-                ry, oy = y.resolve()
-                assert rx.dtype == ry.dtype
-                s = op.slice
-                s.x, s.y = self._ptr(rx, i, "x"), self._ptr(ry, i, "y")
-                s.N, s.H, s.W, s.C = x.N, x.H, x.W, x.C
-                s.x_ld, s.x_coff, s.y_ld, s.y_coff, s.dtype = rx.ld, ox, ry.ld, oy, rx.dtype
+        self.op_info = [_op_info(kind, a) for kind, a in g.ops]   # per op: label, algorithmic flops and bytes
+        self.arenas, self.op_lists = [], []
+        for r in range(replicas):
+            arena = {}
+            for st in g.storages:
+                root, _ = st.root()
+                if root is st and not st.external:
+                    arena[st] = torch.empty(st.N, st.H, st.W, st.ld, device=g.device, dtype=_TORCH_DT[st.dtype])
+            self.arenas.append(arena)
+            ops = (_ffi.Op * n)()
+            for i, (kind, a) in enumerate(g.ops):
+                self._fill(ops[i], i, kind, a, arena, record=(r == 0))
+            self.op_lists.append(ops)
+        self.ops = self.op_lists[0]
+        self._lists = (C.POINTER(_ffi.Op) * replicas)(*[C.cast(o, C.POINTER(_ffi.Op)) for o in self.op_lists])
+        self._counts = (C.c_int * replicas)(*([n] * replicas))
 
-    def _ptr(self, root, i, field):
+    # ---- op records ------------------------------------------------------------------------------------
+    def _ptr(self, root, arena, i, field, record):
         if root.external:
-            self.patch_out.append((i, field, root))
+            if record:
+                self.patch_out.append((i, field, root))
             return 0
-        return root.tensor.data_ptr()
+        return arena[root].data_ptr()
 
-    def _fill_conv(self, i, op, a):
+    def _fill(self, op, i, kind, a, arena, record):
+        if kind == "conv":
+            self._fill_conv(op, i, a, arena, record)
+        elif kind == "focus_conv":
+            op.kind = _ffi.OP_FOCUS_CONV
+            d, pc = op.conv, a["pc"]
+            root, off = a["y"].resolve()
+            d.y, d.w, d.bias = self._ptr(root, arena, i, "cy", record), pc.w.data_ptr(), pc.b.data_ptr()
+            d.N, d.H, d.W, d.Cin = a["N"], a["H"], a["W"], a["C"]
+            d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, 3, 3, 1, 1
+            d.Ho, d.Wo = a["H"] // 2, a["W"] // 2
+            d.y_ld, d.y_coff, d.kp, d.cout_pad = root.ld, off, pc.kp, pc.cout_pad
+            d.act, d.slope, d.in_dtype, d.out_dtype = a["act"], a["slope"], _ffi.BF16, root.dtype
+            op.iarg3 = a["src_dtype"]
+        elif kind == "nchw2nhwc":
+            op.kind = _ffi.OP_NCHW2NHWC
+            root, off = a["y"].resolve()
+            sl = op.slice
+            sl.y = self._ptr(root, arena, i, "y", record)
+            sl.N, sl.C, sl.H, sl.W = a["N"], a["C"], a["H"], a["W"]
+            sl.y_ld, sl.y_coff, sl.dtype = root.ld, off, root.dtype
+            op.iarg, op.iarg2, op.iarg3 = a["focus"], a["c_pad"], a["src_dtype"]
+        elif kind == "nhwc2nchw":
+            op.kind = _ffi.OP_NHWC2NCHW
+            x = a["x"]
+            root, off = x.resolve()
+            sl = op.slice
+            sl.x = self._ptr(root, arena, i, "x", record)
+            sl.N, sl.C, sl.H, sl.W = x.N, x.C, x.H, x.W
+            sl.x_ld, sl.x_coff, sl.dtype = root.ld, off, root.dtype
+            op.iarg3 = a["dst_dtype"]
+            if record:
+                self.nchw_out.append((i, a["name"], (x.N, x.C, x.H, x.W), _TORCH_DT[a["dst_dtype"]]))
+        else:
+            op.kind = {"maxpool2": _ffi.OP_MAXPOOL2, "maxpool2s1": _ffi.OP_MAXPOOL2S1, "spp": _ffi.OP_SPP,
+                       "upsample": _ffi.OP_UPSAMPLE, "space2depth": _ffi.OP_SPACE2DEPTH,
+                       "copy": _ffi.OP_COPY}[kind]
+            op.iarg = a["iarg"]
+            x, y = a["x"], a["y"]
+            rx, ox = x.resolve()
+            ry, oy = y.resolve()
+            assert rx.dtype == ry.dtype
+            sl = op.slice
+            sl.x, sl.y = self._ptr(rx, arena, i, "x", record), self._ptr(ry, arena, i, "y", record)
+            sl.N, sl.H, sl.W, sl.C = x.N, x.H, x.W, x.C
+            sl.x_ld, sl.x_coff, sl.y_ld, sl.y_coff, sl.dtype = rx.ld, ox, ry.ld, oy, rx.dtype
+
+    def _fill_conv(self, op, i, a, arena, record):
         op.kind = _ffi.OP_CONV
         d = op.conv
         x, y, res, pc = a["x"], a["y"], a["res"], a["pc"]
         rx, ox = x.resolve()
         ry, oy = y.resolve()
-        d.x = self._ptr(rx, i, "cx")
-        d.y = self._ptr(ry, i, "cy")
+        d.x = self._ptr(rx, arena, i, "cx", record)
+        d.y = self._ptr(ry, arena, i, "cy", record)
         d.w, d.bias = pc.w.data_ptr(), pc.b.data_ptr()
         d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
         d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, pc.KH, pc.KW, a["stride"], a["pad"]
@@ -367,7 +385,7 @@ class Plan:
         if res is not None:
             rr, orr = res.resolve()
             assert rr.dtype == rx.dtype
-            d.res, d.res_ld, d.res_coff = self._ptr(rr, i, "cres"), rr.ld, orr
+            d.res, d.res_ld, d.res_coff = self._ptr(rr, arena, i, "cres", record), rr.ld, orr
         d.kp, d.cout_pad = pc.kp, pc.cout_pad
         d.act, d.slope, d.res_mode = a["act"], a["slope"], a["res_mode"]
         d.in_dtype, d.out_dtype = rx.dtype, ry.dtype
@@ -380,58 +398,100 @@ class Plan:
         if y.st is ry and y.coff == 0 and pc.Cout % vec and _round_up(pc.Cout, vec) <= min(ry.ld, pc.cout_pad):
             d.cout_store = _round_up(pc.Cout, vec)
 
+    # ---- execution -------------------------------------------------------------------------------------
     def run(self, *xs, timer=None, first_mark=0):
         """xs: the NCHW CUDA inputs (fp32 or bf16; other dtypes are converted to fp32), in the order
-        they were declared.  Returns {name: tensor} of the plan's outputs.  `timer` (a ydet_timer handle):
-        record an event before the first and after every op into marks first_mark.. (see bench.py)."""
+        they were declared.  Returns {name: tensor} of the plan's outputs.  `timer` (a ydet_timer handle, plans with
+        one replica only): record an event before the first and after every op into marks first_mark.."""
         lib = _ffi.lib()
+        R = self.R
         assert len(xs) == len(self.patch_in), f"plan takes {len(self.patch_in)} inputs"
+        assert timer is None or R == 1, "per-op timing needs an unsplit plan"
         outs = {}
         held = []
-        for st in self._ext_storages:
-            st.tensor = torch.empty(st.N, st.H, st.W, st.ld, device=self.device, dtype=_TORCH_DT[st.dtype])
+        ext = {st: torch.empty(st.N * R, st.H, st.W, st.ld, device=self.device, dtype=_TORCH_DT[st.dtype])
+               for st in self._ext_storages}
         for i, x in zip(self.patch_in, xs):
             if x.dtype not in (torch.float32, torch.bfloat16):
                 x = x.float()
             x = x.contiguous()
             held.append(x)
-            op = self.ops[i]
-            if op.kind == _ffi.OP_FOCUS_CONV:
-                want = (op.conv.N, op.conv.Cin, op.conv.H, op.conv.W)
-                assert tuple(x.shape) == want, f"plan built for {want}, got {tuple(x.shape)}"
-                op.conv.x = x.data_ptr()
-            else:
-                want = (op.slice.N, op.slice.C, op.slice.H, op.slice.W)
-                assert tuple(x.shape) == want, f"plan built for {want}, got {tuple(x.shape)}"
-                op.slice.x = x.data_ptr()
-            op.iarg3 = _ffi.BF16 if x.dtype == torch.bfloat16 else _ffi.F32
+            op0 = self.op_lists[0][i]
+            focus = op0.kind == _ffi.OP_FOCUS_CONV
+            per = (op0.conv.N, op0.conv.Cin, op0.conv.H, op0.conv.W) if focus else (op0.slice.N, op0.slice.C, op0.slice.H, op0.slice.W)
+            want = (per[0] * R,) + per[1:]
+            assert tuple(x.shape) == want, f"plan built for {want}, got {tuple(x.shape)}"
+            step = per[0] * per[1] * per[2] * per[3] * x.element_size()
+            for r in range(R):
+                op = self.op_lists[r][i]
+                if focus:
+                    op.conv.x = x.data_ptr() + r * step
+                else:
+                    op.slice.x = x.data_ptr() + r * step
+                op.iarg3 = _ffi.BF16 if x.dtype == torch.bfloat16 else _ffi.F32
         for i, field, root in self.patch_out:
-            ptr = root.tensor.data_ptr()
-            op = self.ops[i]
-            if field == "x":
-                op.slice.x = ptr
-            elif field == "y":
-                op.slice.y = ptr
-            elif field == "cx":
-                op.conv.x = ptr
-            elif field == "cy":
-                op.conv.y = ptr
-            else:
-                op.conv.res = ptr
+            t = ext[root]
+            step = root.N * root.H * root.W * root.ld * t.element_size()
+            for r in range(R):
+                ptr = t.data_ptr() + r * step
+                op = self.op_lists[r][i]
+                if field == "x":
+                    op.slice.x = ptr
+                elif field == "y":
+                    op.slice.y = ptr
+                elif field == "cx":
+                    op.conv.x = ptr
+                elif field == "cy":
+                    op.conv.y = ptr
+                else:
+                    op.conv.res = ptr
         for i, name, shape, dt in self.nchw_out:
-            t = torch.empty(shape, device=self.device, dtype=dt)
-            self.ops[i].slice.y = t.data_ptr()
+            t = torch.empty((shape[0] * R,) + shape[1:], device=self.device, dtype=dt)
+            step = shape[0] * shape[1] * shape[2] * shape[3] * t.element_size()
+            for r in range(R):
+                self.op_lists[r][i].slice.y = t.data_ptr() + r * step
             outs[name] = t
         with torch.cuda.device(self.device):
-            if timer is None:
-                _ffi.check(lib.ydet_run_ops(self.ops, len(self.ops), _ffi.current_stream()), "ydet_run_ops")
-            else:
+            if timer is not None:
                 _ffi.check(lib.ydet_run_ops_timed(self.ops, len(self.ops), _ffi.current_stream(), timer, first_mark),
                            "ydet_run_ops_timed")
+            elif R == 1:
+                _ffi.check(lib.ydet_run_ops(self.ops, len(self.ops), _ffi.current_stream()), "ydet_run_ops")
+            else:
+                _ffi.check(lib.ydet_run_op_lists(self._lists, self._counts, R, _ffi.current_stream()), "ydet_run_op_lists")
         for name, t in self.g.outputs.items():
             root, off = t.resolve()
-            outs[name] = root.tensor[..., off:off + t.C]
+            if root.external:
+                outs[name] = ext[root][..., off:off + t.C]
+            elif R == 1:
+                outs[name] = self.arenas[0][root][..., off:off + t.C]
+            else:
+                outs[name] = torch.cat([ar[root][..., off:off + t.C] for ar in self.arenas], 0)
         return outs
+
+
+_batch_split = 1
+
+
+def set_batch_split(n):
+    """How many side-by-side launch lists a forward pass is split into along the batch (1 = off, the default).
+    A split is only applied to batches of at least 8 images per part.  Two half-batch lists on two streams ran the
+    YOLOv5s 640x640 batch-64 conv stack about 8 % faster than one list (their kernels fill each other's partial
+    waves of workgroups); per-kernel timings are then no longer those of a kernel that owns the GPU."""
+    global _batch_split
+    if n not in (1, 2, 4):
+        raise ValueError("batch split must be 1, 2 or 4")
+    _batch_split = n
+
+
+def build_plan(device, compute, N, lower):
+    """Plan a forward pass for a batch of N: lower(g, n) emits the network for a batch of n into graph g."""
+    R = _batch_split
+    while R > 1 and (N % R or N // R < 8):
+        R //= 2
+    g = Graph(device, compute)
+    lower(g, N // R)
+    return Plan(g, R)
 
 
 def conv_tile(cout):
@@ -453,7 +513,7 @@ def _op_info(kind, a):
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
-        return dict(kind="conv", label="focus_conv3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
+        return dict(kind="conv", label="conv_focus3x3<nchw>", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
                     bytes=a["N"] * a["C"] * a["H"] * a["W"] * 4 + y.N * y.H * y.W * y.C * esz(y),
                     shape=(a["N"], a["H"], a["W"], a["C"], pc.Cout, 3, 1))
     if kind == "nchw2nhwc":

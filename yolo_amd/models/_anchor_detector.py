@@ -54,12 +54,13 @@ class AnchorDetector(engine.AcceleratedModule):
         compute = engine.compute_dtype_for(self)
         key = (tuple(x.shape), compute, x.device.index)
 
-        def build():
-            g = engine.Graph(x.device, compute)
-            t = g.input_nchw(*x.shape)
+        def lower(g, n):
+            t = g.input_nchw(n, *x.shape[1:])
             for i, h in enumerate(self._heads(_HeadLowerOps(g), t)):
                 g.output(f"head{i}", h)
-            return g.finalize()
+
+        def build():
+            return engine.build_plan(x.device, compute, x.shape[0], lower)
 
         outs = self._plans().get(key, build).run(x)
         return [outs[f"head{i}"] for i in range(len(outs))]

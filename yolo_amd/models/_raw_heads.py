@@ -18,12 +18,13 @@ class RawHeadDetector(engine.AcceleratedModule):
         compute = engine.compute_dtype_for(self)
         key = (tuple(x.shape), compute, x.device.index)
 
-        def build():
-            g = engine.Graph(x.device, compute)
-            t = g.input_nchw(*x.shape, focus=self.focus_input)
+        def lower(g, n):
+            t = g.input_nchw(n, *x.shape[1:], focus=self.focus_input)
             for i, h in enumerate(self._heads(_HeadLowerOps(g), t)):
                 g.output(f"head{i}", h)
-            return g.finalize()
+
+        def build():
+            return engine.build_plan(x.device, compute, x.shape[0], lower)
 
         with torch.no_grad():
             outs = self._plans().get(key, build).run(x)

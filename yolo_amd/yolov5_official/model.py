@@ -333,9 +333,7 @@ class Model(engine.AcceleratedModule):
         key = (tuple(x.shape), compute, x.device.index)
 
         def build():
-            g = engine.Graph(x.device, compute)
-            self._lower(g, *x.shape)
-            return g.finalize()
+            return engine.build_plan(x.device, compute, x.shape[0], lambda g, n: self._lower(g, n, *x.shape[1:]))
 
         outs = self._plans().get(key, build).run(x)
         z, xs = det.decode([outs[f"head{i}"] for i in range(det.nl)])
