@@ -134,6 +134,17 @@ def main():
         elapsed = float(t.item())
 
     # ---- per-kernel device times from the events recorded during the timed steps ----------------------
+    # An interval between two events holds one kernel plus the events' own cost; that cost is measured on the same
+    # stream (50 events back to back, nothing between them) and taken off every interval.
+    ncal = 50
+    cal = lib.ydet_timer_create(ncal)
+    for i in range(ncal):
+        _ffi.check(lib.ydet_run_ops_timed(None, 0, _ffi.current_stream(), cal, i), "ydet_run_ops_timed")
+    torch.cuda.synchronize()
+    gaps = (ctypes.c_float * (ncal - 1))()
+    _ffi.check(lib.ydet_timer_elapsed(cal, 0, ncal - 1, gaps), "ydet_timer_elapsed")
+    lib.ydet_timer_destroy(cal)
+    event_ms = sorted(gaps)[(ncal - 1) // 2]
     plan = plan_holder["plan"]
     per_label = {}
     buf = (ctypes.c_float * n_ops)()
@@ -141,7 +152,7 @@ def main():
         _ffi.check(lib.ydet_timer_elapsed(timer, k * (n_ops + 1), n_ops, buf), "ydet_timer_elapsed")
         for i, info in enumerate(plan.op_info):
             d = per_label.setdefault(info["label"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
-            d["ms"] += buf[i]; d["launches"] += 1; d["flops"] += info["flops"]; d["bytes"] += info["bytes"]
+            d["ms"] += max(buf[i] - event_ms, 1e-4); d["launches"] += 1; d["flops"] += info["flops"]; d["bytes"] += info["bytes"]
     if args.per_op and rank == 0:
         per_op = [0.0] * n_ops
         for k in range(args.steps):
@@ -173,6 +184,17 @@ def main():
     decode_bytes = 2.0 * args.batch * n_boxes * 85 * 4
     nms_bytes = args.batch * n_boxes * 85 * 4 + args.batch * 300 * 6 * 4
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
+    # from the committed summary of the separate rocprofv3 --pmc passes over this same command (tools/profile_round.sh)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        if tj.get("batch") == args.batch and tj.get("size") == args.size and dom_label in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom_label]["hbm_bytes_per_launch"]
+            traffic_src = tj.get("source")
+
     result = {
         "metric": "images/sec (fwd+decode+NMS) YOLOv5s 640 bs64",
         "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -191,9 +213,12 @@ def main():
                    "images_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}", "batch_split": args.split,
                    "weights": "seeded synthetic (yolo_amd.synthetic.init_deterministic)"},
         "roofline": {"bound": "mfma", "kernel": dom_label, "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(dom_tf / peak, 4), "traffic": None,
+                     "frac": round(dom_tf / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
-                     "flops_per_launch": dom["flops"] / dom["launches"]},
+                     "launches_per_step": dom["launches"] // args.steps,
+                     "flops_per_launch": dom["flops"] / dom["launches"],
+                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+                     "event_overhead_us": round(event_ms * 1e3, 2)},
         "conv_stack": {"tflops": round(stack_tf, 2), "mfma_util_frac": round(stack_tf / peak, 4),
                        "ms_per_step": round(conv_ms / args.steps, 3),
                        "gflop_per_image": round(conv_flops / args.steps / args.batch / 1e9, 3)},

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output into the summaries kept under profiles/.
+
+    rocprof_summary.py stats   <kernel_trace.csv>                      -> per-kernel duration statistics (CSV on stdout)
+    rocprof_summary.py traffic <fetch_counter.csv> <write_counter.csv> <batch> <size>  -> HBM traffic per kernel (JSON)
+
+Kernel symbols are also given the label bench.py uses for them (conv_dma<128x128,bf16->bf16>, ...), so that the two
+sources can be compared line by line.  FETCH_SIZE / WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE tallies the
+128-byte requests of a wide coalesced read at 64 bytes, so the read side is doubled.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def label_of(name):
+    m = re.search(r"conv_(dma|generic)_kernel", name)
+    if m:
+        kind = m.group(1)
+        if "DF16bDF16b" in name:
+            dts = "bf16->bf16"
+        elif "DF16bf" in name or "_Accum" in name:   # the demangler prints <__bf16, float> as "bool _Accum"
+            dts = "bf16->f32"
+        else:
+            dts = "f32->f32"
+        nums = re.findall(r"Li(\d+)E", name) or re.findall(r"(?<![\w.])(\d+)(?=[,>])", name)
+        bn, bm = nums[0], nums[1]
+        if kind == "dma":
+            return f"conv_dma<{bn}x{bm},{dts}>"
+        one = "Lb1E" in name or re.search(r"true>", name)
+        return f"conv_generic<{bn}x{bm},{'1x1' if one else 'kxk'},{dts}>"
+    for key, lab in (("focus_conv3x3", "conv_focus3x3"), ("decode_v5", "decode_v5"), ("v5_pick", "nms_v5_pick"),
+                     ("v5_nms", "nms_v5_greedy"), ("v5_rank", "nms_v5_rank"), ("v5_rowmax", "nms_v5_rowmax"),
+                     ("v5_exact", "nms_v5_exact_select"), ("spp_lds", "spp"), ("upsample2x", "upsample"),
+                     ("nchw_to_nhwc", "nchw2nhwc")):
+        if key in name:
+            return lab
+    return ""
+
+
+def stats(path):
+    rows = list(csv.DictReader(open(path)))
+    agg = collections.defaultdict(list)
+    for r in rows:
+        agg[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in agg.values()) or 1
+    print('"Label","Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"')
+    for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print(f'"{label_of(name)}","{name}",{len(v)},{sum(v)},{sum(v) / len(v):.1f},{100.0 * sum(v) / total:.2f},{min(v)},{max(v)}')
+
+
+def traffic(fetch_csv, write_csv, batch, size):
+    def per_kernel(path, counter):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        return agg
+    fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    out = {}
+    for name in fetch:
+        lab = label_of(name)
+        if not lab:
+            continue
+        f, w = fetch[name], write.get(name, [0.0])
+        d = out.setdefault(lab, dict(launches=0, fetch_kb_raw=0.0, write_kb=0.0))
+        d["launches"] += len(f)
+        d["fetch_kb_raw"] += sum(f)
+        d["write_kb"] += sum(w) * (len(f) / max(len(w), 1))
+    for d in out.values():
+        n = d["launches"]
+        d["fetch_kb_raw"] = round(d["fetch_kb_raw"] / n, 1)
+        d["write_kb"] = round(d["write_kb"] / n, 1)
+        d["hbm_bytes_per_launch"] = round((2.0 * d["fetch_kb_raw"] + d["write_kb"]) * 1024)
+    print(json.dumps(dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --no-cpu` (separate runs); "
+                                 "kilobytes per launch, read side doubled (gfx950 tallies 128-B requests at 64 B)",
+                          batch=int(batch), size=int(size), kernels=out), indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        traffic(*sys.argv[2:6])

@@ -499,21 +499,32 @@ def conv_tile(cout):
     return (32, 256) if cout <= 32 else (64, 128) if cout <= 64 else (128, 128)
 
 
+def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt):
+    """Name of the kernel instantiation ydet_conv2d_nhwc launches for this shape (mirrors launch_tile() in
+    csrc/conv.hip), so that timings keyed by it line up with a profiler's per-symbol statistics."""
+    bn, bm = conv_tile(cout)
+    bk = 32 if in_dt == _ffi.BF16 else 16
+    dts = f"{'bf16' if in_dt == _ffi.BF16 else 'f32'}->{'bf16' if out_dt == _ffi.BF16 else 'f32'}"
+    if bn >= 64 and cin_phys % bk == 0 and kh * kw <= 32:
+        return f"conv_dma<{bn}x{bm},{dts}>"
+    one = kh == 1 and kw == 1 and pad == 0
+    return f"conv_generic<{bn}x{bm},{'1x1' if one else 'kxk'},{dts}>"
+
+
 def _op_info(kind, a):
     esz = lambda t: 2 if t.dtype == _ffi.BF16 else 4
     if kind == "conv":
         x, y, pc = a["x"], a["y"], a["pc"]
-        bn, bm = conv_tile(pc.Cout)
-        one = pc.KH == 1 and pc.KW == 1 and a["pad"] == 0
         flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.cin_real * pc.KH * pc.KW
         nbytes = x.N * x.H * x.W * x.C * esz(x) + y.N * y.H * y.W * y.C * esz(y) + pc.Cout * pc.KH * pc.KW * x.C * esz(x)
         if a["res"] is not None:
             nbytes += y.N * y.H * y.W * y.C * esz(x)
-        return dict(kind="conv", label=f"conv_igemm<{bn}x{bm},{'1x1' if one else 'kxk'}>", flops=flops, bytes=nbytes,
+        return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype), flops=flops,
+                    bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
-        return dict(kind="conv", label="conv_focus3x3<nchw>", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
+        return dict(kind="conv", label="conv_focus3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
                     bytes=a["N"] * a["C"] * a["H"] * a["W"] * 4 + y.N * y.H * y.W * y.C * esz(y),
                     shape=(a["N"], a["H"], a["W"], a["C"], pc.Cout, 3, 1))
     if kind == "nchw2nhwc":
