@@ -325,6 +325,9 @@ CONV_CASES = [
     (2, 40, 40, 64, 128, 3, 2, 1, "silu", None),
     (1, 6, 6, 1024, 512, 1, 1, 0, "silu", None),
     (2, 11, 11, 40, 40, 5, 1, 2, "none", None),          # 5x5 kernel
+    # grids where the dispatcher picks the 128 x 256 eight-wave tile (800 -> 400 workgroups), ragged last tile
+    (16, 80, 79, 64, 128, 3, 1, 1, "silu", "after"),
+    (16, 80, 80, 128, 250, 1, 1, 0, "none", None),
 ]
 
 
@@ -365,6 +368,8 @@ def test_conv_against_torch(compute, tol, case):
     out = _run_graph(build, *([x, r] if resk else [x]), compute=compute)
     assert out["y"].shape == ref.shape
     assert rel_err(out["y"].float().cpu(), ref) < tol
+    if N == 16:
+        assert engine.conv_kernel_label(Cin, Cout, k, k, p, _ffi.BF16, _ffi.BF16, M=N * Ho * Wo).startswith("conv_dma<128x256")
 
 
 def test_conv_argument_validation():

@@ -28,6 +28,7 @@
 //                       contiguous channel run.
 //   conv_generic_kernel any Cin that is a multiple of the chunk: per-thread tap tracking, global ->
 //                       registers -> LDS, two stages.
+#include <math.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -358,14 +359,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
-__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
-    static_assert(WARPS_N * WARPS_M == 4, "four waves per workgroup");
+__global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const ConvArgs a) {
+    constexpr int NW = WARPS_N * WARPS_M;         // waves per workgroup (4 or 8)
+    constexpr int NT = 64 * NW;
+    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
     constexpr int EPC = 16 / (int)sizeof(TIN);
     constexpr int BK = 4 * EPC;
     constexpr int WN = BN / WARPS_N, WM = BM / WARPS_M;
     constexpr int FN = WN / 16, FM = WM / 16;
-    constexpr int WROWS = BN < 64 ? 64 : BN;      // weight rows staged (>= 64 so every wave stages whole groups)
-    constexpr int WJ = WROWS / 64, XJ = BM / 64;  // 16-row groups per wave: weights, pixels
+    constexpr int WROWS = BN < 16 * NW ? 16 * NW : BN;   // weight rows staged (so every wave stages whole 16-row groups)
+    constexpr int WJ = WROWS / (16 * NW), XJ = BM / (16 * NW);  // 16-row groups per wave: weights, pixels
+    static_assert(WJ >= 1 && XJ >= 1 && WROWS % (16 * NW) == 0 && BM % (16 * NW) == 0, "tile too small for the wave count");
     constexpr int LPT = WJ + XJ;                  // LDS-DMA instructions per wave and tile
     constexpr int STAGE = (WROWS + BM) * 64;
     constexpr int NSTAGE = 3;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     }
 
     // ---- staging roles ------------------------------------------------------------------------------
-    // wave-instruction j of a wave fills LDS rows (j*4 + wave)*16 .. +15 of the weight (j < WJ) or pixel
+    // wave-instruction j of a wave fills LDS rows (j*NW + wave)*16 .. +15 of the weight (j < WJ) or pixel
     // image; lane l lands at physical chunk l&3 of row l>>2 and therefore fetches logical chunk
     // (l&3) ^ F[(l>>4)&3] (the swizzle lives on the source address, the LDS image stays lane-linear).
     const int srow = lane >> 2;
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     const char* wsrc[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j)
-        wsrc[j] = a.w + ((size_t)(n0 + (j * 4 + wave) * 16 + srow) * a.kp + lchunk * EPC) * sizeof(TIN);
+        wsrc[j] = a.w + ((size_t)(n0 + (j * NW + wave) * 16 + srow) * a.kp + lchunk * EPC) * sizeof(TIN);
 
     const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     const char* xsrc[XJ];
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     const int taps = a.KH * a.KW;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-        const long long m = m0 + (j * 4 + wave) * 16 + srow;
+        const long long m = m0 + (j * NW + wave) * 16 + srow;
         const bool okm = m < a.M;
         const long long mm = okm ? m : 0;
         if (pointwise) {
@@ -453,13 +457,13 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + woff),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + j * (NW * 1024)), 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const bool ok = (xmask[j] >> tap) & 1u;
             const char* src = ok ? xsrc[j] + tapoff : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + WROWS * 64 + j * 4096), 16,
+                                             (__attribute__((address_space(3))) void*)(dst + WROWS * 64 + j * (NW * 1024)), 16,
                                              0, 0);
         }
         ++ktile;
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
                 YDET_STAMP(21);
                 __syncthreads();
                 YDET_STAMP(29);
-                for (int idx = tid; idx < PM * PIECES; idx += 256) {
+                for (int idx = tid; idx < PM * PIECES; idx += NT) {
                     const int pl = idx / PIECES, piece = idx - pl * PIECES;
                     const long long m = m0 + pass * PM + pl;
                     const int co = n0 + piece * V;
@@ -589,27 +593,54 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     // uniform-tap LDS-DMA kernel; the 32-channel tile keeps the register-staged kernel (measured faster there:
     // its weight image is half padding under the DMA group layout)
     if (BN >= 64 && a.Cin % BK == 0 && a.KH * a.KW <= 32) {
-        constexpr int WROWS = BN < 64 ? 64 : BN;
+        constexpr int NW = WARPS_N * WARPS_M;
+        constexpr int WROWS = BN < 16 * NW ? 16 * NW : BN;
         const size_t lds_dma = 3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float);
         a.lds_epilogue = (a.y_ld % (16 / (int)sizeof(TOUT)) == 0 && a.y_coff % (16 / (int)sizeof(TOUT)) == 0 &&
                           a.cout_store % (16 / (int)sizeof(TOUT)) == 0)
                              ? 1
                              : 0;
-        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M>), dim3((unsigned)nblk), dim3(256),
+        if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
+            static const hipError_t attr = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float)));
+            if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        }
+        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M>), dim3((unsigned)nblk), dim3(64 * NW),
                            lds_dma, stream, a);
         YDET_CHECK_LAUNCH("conv_dma_kernel");
         return YDET_OK;
     }
-    const size_t lds = 2 * (size_t)(BN + BM) * 64;
-    const bool is1x1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
-    if (is1x1)
-        hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, true>), dim3((unsigned)nblk),
-                           dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
-                           dim3(256), lds, stream, a);
-    YDET_CHECK_LAUNCH("conv_generic_kernel");
-    return YDET_OK;
+    if constexpr (WARPS_N * WARPS_M != 4) {
+        return fail(YDET_ERR_ARG, "conv: the %dx%d tile needs Cin to be a multiple of %d", BN, BM, BK);
+    } else {
+        const size_t lds = 2 * (size_t)(BN + BM) * 64;
+        const bool is1x1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
+        if (is1x1)
+            hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, true>), dim3((unsigned)nblk),
+                               dim3(256), lds, stream, a);
+        else
+            hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
+                               dim3(256), lds, stream, a);
+        YDET_CHECK_LAUNCH("conv_generic_kernel");
+        return YDET_OK;
+    }
+}
+
+// 128 x 256 tile (8 waves, 2 workgroups per CU) or 128 x 128 (4 waves, 3 per CU)?  The wide tile moves 25 % fewer
+// bytes through the LDS-DMA path per FLOP, which is what bounds a K step, and halves the number of workgroups.  It
+// pays when that turns a grid slightly larger than the resident slots (a second, nearly empty round) into one that
+// fits, and never when it leaves CUs without work.  Measured on MI355X (256 CUs); mirrored by
+// yolo_amd/engine.py:conv_kernel_label.
+static bool wide_tile_pays(long long M, int Cout, int K, bool dma_ok) {
+    if (!dma_ok) return false;                       // the wide tile exists for the LDS-DMA kernel only
+    const long long tn = (Cout + 127) / 128;
+    const double b128 = (double)((M + 127) / 128 * tn), b256 = (double)((M + 255) / 256 * tn);
+    if (b256 < 256.0) return false;
+    const double w128 = b128 / 768.0, w256 = b256 / 512.0;
+    const double r128 = ceil(w128) / w128, r256 = ceil(w256) / w256;   // >= 1: slots paid for / slots used
+    const double gain = K >= 256 ? 0.85 : 1.0;
+    return r256 * gain < r128 - 0.02;
 }
 
 template <typename TIN, typename TOUT>
@@ -623,10 +654,13 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
             if (bn == 64 && bm == 128) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
             if (bn == 128 && bm == 128) return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
             if (bn == 128 && bm == 64) return launch_tile<TIN, TOUT, 128, 64, 2, 2>(a, stream);
+            if (bn == 128 && bm == 256) return launch_tile<TIN, TOUT, 128, 256, 2, 4>(a, stream);
         }
     }
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
     if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
+    if (wide_tile_pays(a.M, a.Cout, a.KH * a.KW * a.Cin, a.Cin % (64 / (int)sizeof(TIN)) == 0 && a.KH * a.KW <= 32))
+        return launch_tile<TIN, TOUT, 128, 256, 2, 4>(a, stream);
     return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
 }
 

@@ -499,13 +499,27 @@ def conv_tile(cout):
     return (32, 256) if cout <= 32 else (64, 128) if cout <= 64 else (128, 128)
 
 
-def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt):
-    """Name of the kernel instantiation ydet_conv2d_nhwc launches for this shape (mirrors launch_tile() in
-    csrc/conv.hip), so that timings keyed by it line up with a profiler's per-symbol statistics."""
+def _wide_tile_pays(M, cout, K):
+    """Mirror of wide_tile_pays() in csrc/conv.hip."""
+    tn = (cout + 127) // 128
+    b128, b256 = (M + 127) // 128 * tn, (M + 255) // 256 * tn
+    if b256 < 256:
+        return False
+    w128, w256 = b128 / 768.0, b256 / 512.0
+    r128, r256 = math.ceil(w128) / w128, math.ceil(w256) / w256
+    return r256 * (0.85 if K >= 256 else 1.0) < r128 - 0.02
+
+
+def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0):
+    """Name of the kernel instantiation ydet_conv2d_nhwc launches for this shape (mirrors launch_dtype() / launch_tile()
+    in csrc/conv.hip), so that timings keyed by it line up with a profiler's per-symbol statistics."""
     bn, bm = conv_tile(cout)
     bk = 32 if in_dt == _ffi.BF16 else 16
     dts = f"{'bf16' if in_dt == _ffi.BF16 else 'f32'}->{'bf16' if out_dt == _ffi.BF16 else 'f32'}"
-    if bn >= 64 and cin_phys % bk == 0 and kh * kw <= 32:
+    dma = cin_phys % bk == 0 and kh * kw <= 32
+    if bn == 128 and dma and _wide_tile_pays(M, cout, kh * kw * cin_phys):
+        bm = 256
+    if bn >= 64 and dma:
         return f"conv_dma<{bn}x{bm},{dts}>"
     one = kh == 1 and kw == 1 and pad == 0
     return f"conv_generic<{bn}x{bm},{'1x1' if one else 'kxk'},{dts}>"
@@ -519,7 +533,8 @@ def _op_info(kind, a):
         nbytes = x.N * x.H * x.W * x.C * esz(x) + y.N * y.H * y.W * y.C * esz(y) + pc.Cout * pc.KH * pc.KW * x.C * esz(x)
         if a["res"] is not None:
             nbytes += y.N * y.H * y.W * y.C * esz(x)
-        return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype), flops=flops,
+        return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W),
+                    flops=flops,
                     bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
     if kind == "focus_conv":
