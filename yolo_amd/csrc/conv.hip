@@ -392,14 +392,17 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     const int n0 = tile_n * BN;
     const long long m0 = tile_m * BM;
 
-    // per-channel epilogue constants of this tile, parked behind the ring: visible after the first barrier of the
-    // K loop, read after the last (a global load per use would put its latency into every epilogue iteration)
+    // per-channel epilogue constants of this tile: fetched into registers now (nothing waits for them here -- a
+    // dependent LDS store would put a cold global load's latency in front of the K loop) and parked behind the ring
+    // right after the K loop, where the epilogue reads them
+    YDET_STAMP(22);
     float* cst = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
+    float cst_b = 0.f, cst_ps = 0.f, cst_pb = 0.f;
     if (tid < BN) {
-        cst[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+        if (a.bias) cst_b = a.bias[n0 + tid];
         if (a.post_scale) {
-            cst[BN + tid] = a.post_scale[n0 + tid];
-            cst[2 * BN + tid] = a.post_shift[n0 + tid];
+            cst_ps = a.post_scale[n0 + tid];
+            cst_pb = a.post_shift[n0 + tid];
         }
     }
 
@@ -414,11 +417,11 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     for (int j = 0; j < WJ; ++j)
         wsrc[j] = a.w + ((size_t)(n0 + (j * NW + wave) * 16 + srow) * a.kp + lchunk * EPC) * sizeof(TIN);
 
+    YDET_STAMP(23);
     const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     const char* xsrc[XJ];
     unsigned xmask[XJ];
     const int HoWo = a.Ho * a.Wo;
-    const int taps = a.KH * a.KW;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
         const long long m = m0 + (j * NW + wave) * 16 + srow;
@@ -428,15 +431,19 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
             xsrc[j] = a.x + ((size_t)mm * a.x_ld + a.x_coff + lchunk * EPC) * sizeof(TIN);
             xmask[j] = okm ? 1u : 0u;
         } else {
-            const int n = (int)(mm / HoWo);
-            const int rem = (int)(mm - (long long)n * HoWo);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            // M < 2^31 (checked on the host): 32-bit divisions, and no division at all in the tap walk
+            const unsigned mu = (unsigned)mm;
+            const int n = (int)(mu / (unsigned)HoWo);
+            const int rem = (int)(mu - (unsigned)n * (unsigned)HoWo);
+            const int ho = (int)((unsigned)rem / (unsigned)a.Wo), wo = rem - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
             unsigned mk = 0;
             if (okm) {
-                for (int t = 0; t < taps; ++t) {
-                    const int kh = t / a.KW, kw = t - kh * a.KW;
-                    if ((unsigned)(hi0 + kh) < (unsigned)a.H && (unsigned)(wi0 + kw) < (unsigned)a.W) mk |= 1u << t;
+                unsigned bit = 1u;
+                for (int kh = 0; kh < a.KH; ++kh) {
+                    const bool rowok = (unsigned)(hi0 + kh) < (unsigned)a.H;
+                    for (int kw = 0; kw < a.KW; ++kw, bit <<= 1)
+                        if (rowok && (unsigned)(wi0 + kw) < (unsigned)a.W) mk |= bit;
                 }
             }
             xmask[j] = mk;
@@ -445,6 +452,7 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         }
     }
     const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
+    YDET_STAMP(24);
 
     // workgroup-uniform walk over K: tap index and channel offset of the current K-step
     int tap = 0, c0 = 0, kh = 0, kw = 0;
@@ -454,10 +462,16 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     auto issue = [&](int stage) {
         char* dst = smem + stage * STAGE + wave * 1024;
         const long long woff = (long long)ktile * BK * (long long)sizeof(TIN);
+#ifdef YDET_EXP_SKIP_W
+        if (ktile == 0)
+#endif
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + woff),
                                              (__attribute__((address_space(3))) void*)(dst + j * (NW * 1024)), 16, 0, 0);
+#ifdef YDET_EXP_SKIP_PIX   // timing experiment only: pixel rows fetched for the first tap of each channel block only
+        if (tap == 0 || a.KH == 1)
+#endif
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const bool ok = (xmask[j] >> tap) & 1u;
@@ -500,10 +514,19 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         const char* ws = smem + (kt % NSTAGE) * STAGE + (wn * WN) * 64 + fr_off;
         const char* xs = smem + (kt % NSTAGE) * STAGE + WROWS * 64 + (wm * WM) * 64 + fr_off;
         frag_t fa[FN], fb[FM];
+#ifdef YDET_EXP_NO_LDSREAD
+        if (kt == 0) {
+#endif
 #pragma unroll
         for (int i = 0; i < FN; ++i) fa[i] = *reinterpret_cast<const frag_t*>(ws + i * 16 * 64);
 #pragma unroll
         for (int j = 0; j < FM; ++j) fb[j] = *reinterpret_cast<const frag_t*>(xs + j * 16 * 64);
+#ifdef YDET_EXP_NO_LDSREAD
+        }
+#endif
+#ifdef YDET_EXP_NO_MFMA
+        if (kt == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -512,6 +535,12 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 
     // ---- epilogue -------------------------------------------------------------------------------------
     YDET_STAMP(28);
+    if (tid < BN) {
+        cst[tid] = cst_b;
+        cst[BN + tid] = cst_ps;
+        cst[2 * BN + tid] = cst_pb;
+    }
+    __syncthreads();   // constants visible; also: every wave is done with the ring
     const int q = lane >> 4, px = lane & 15;
     with_epilogue_mode(a, [&](auto mode) {
         constexpr int MODE = decltype(mode)::value;
@@ -629,6 +658,7 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
 
 // 128 x 256 tile (8 waves, 2 workgroups per CU) or 128 x 128 (4 waves, 3 per CU)?  The wide tile moves 25 % fewer
 // bytes through the LDS-DMA path per FLOP, which is what bounds a K step, and halves the number of workgroups.  It
+// (bf16 outputs only: an fp32 output tile no longer fits the LDS epilogue in one pass).  It
 // pays when that turns a grid slightly larger than the resident slots (a second, nearly empty round) into one that
 // fits, and never when it leaves CUs without work.  Measured on MI355X (256 CUs); mirrored by
 // yolo_amd/engine.py:conv_kernel_label.
@@ -659,7 +689,7 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
     }
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
     if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
-    if (wide_tile_pays(a.M, a.Cout, a.KH * a.KW * a.Cin, a.Cin % (64 / (int)sizeof(TIN)) == 0 && a.KH * a.KW <= 32))
+    if (sizeof(TOUT) == 2 && wide_tile_pays(a.M, a.Cout, a.KH * a.KW * a.Cin, a.Cin % (64 / (int)sizeof(TIN)) == 0 && a.KH * a.KW <= 32))
         return launch_tile<TIN, TOUT, 128, 256, 2, 4>(a, stream);
     return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
 }
@@ -699,6 +729,7 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
                    "conv: pointers must be 16-byte aligned");
     if (d->res) YDET_CHECK_ARG(d->res_coff >= 0 && d->res_coff + d->Cout <= d->res_ld, "conv: residual slice");
     YDET_CHECK_ARG((long long)d->H * d->W * d->x_ld < (1LL << 31), "conv: one image exceeds 2^31 elements");
+    YDET_CHECK_ARG((long long)d->N * d->Ho * d->Wo < (1LL << 31), "conv: more than 2^31 output pixels");
 
     ConvArgs a;
     a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.res = (const char*)d->res;

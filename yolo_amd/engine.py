@@ -517,7 +517,7 @@ def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0):
     bk = 32 if in_dt == _ffi.BF16 else 16
     dts = f"{'bf16' if in_dt == _ffi.BF16 else 'f32'}->{'bf16' if out_dt == _ffi.BF16 else 'f32'}"
     dma = cin_phys % bk == 0 and kh * kw <= 32
-    if bn == 128 and dma and _wide_tile_pays(M, cout, kh * kw * cin_phys):
+    if bn == 128 and dma and out_dt == _ffi.BF16 and _wide_tile_pays(M, cout, kh * kw * cin_phys):
         bm = 256
     if bn >= 64 and dma:
         return f"conv_dma<{bn}x{bm},{dts}>"
