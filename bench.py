@@ -82,7 +82,7 @@ def main():
         det_head = model.model[-1]
         if ev is not None:
             ev[0].record()
-        z, _ = det_head.decode([outs[f"head{i}"] for i in range(det_head.nl)])
+        z, _ = det_head.finish(outs)
         if ev is not None:
             ev[1].record()
         det, cnt = non_max_suppression_padded(z, 0.001, 0.6, multi_label=True)

@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 3
+#define YDET_ABI_VERSION 4
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -166,6 +166,23 @@ typedef struct {
 int ydet_decode_v5(const ydet_v5_level* levels /* host */, int nl, int N, int na, int no,
                    int grid_transposed, int head_dtype, float* out, float* row_max, void* stream);
 
+/* One pyramid level of Detect as ONE kernel: the bias-only 1x1 prediction convolution (yolov5_official/model.py:42,58
+ * `self.m[i]`) with the eval-mode decode of lines 56-81 in its epilogue.  `d` describes the convolution
+ * (1x1, fp32 output, no activation, Cout = na*no <= 256, weights padded to 256 rows); its output d->y is the raw map
+ * the reference returns as x[i] (NHWC, channel a*no + o).  The decoded rows go to z [N, rows_per_image, no] at rows
+ * level_row_offset + (a*ny + row)*nx + col, and max_c(z[5+c] * z[4]) per row to row_max (may be NULL) -- exactly what
+ * ydet_decode_v5 would produce from d->y.  no <= 128. */
+typedef struct {
+    float* z;
+    float* row_max;
+    int64_t rows_per_image;
+    int32_t level_row_offset;
+    int32_t na, no, ny, nx, grid_transposed;
+    float stride;
+    float anchor_wh[2 * 8];
+} ydet_head_desc;
+int ydet_head_conv_decode(const ydet_conv_desc* d, const ydet_head_desc* head, void* stream);
+
 typedef struct {
     const void* head; /* NHWC head map [N, H, W, ld], channels [A conf | A*nc cls | A*4 box] */
     int32_t H, W, ld;
@@ -239,14 +256,16 @@ typedef enum {
     YDET_OP_NCHW2NHWC = 7,     /* slice: x=src NCHW, C = real channels; iarg = focus, iarg2 = c_pad,
                                   iarg3 = source dtype */
     YDET_OP_NHWC2NCHW = 8,     /* iarg3 = destination dtype */
-    YDET_OP_FOCUS_CONV = 9     /* conv: as ydet_focus_conv3x3_nchw; iarg3 = image dtype */
+    YDET_OP_FOCUS_CONV = 9,    /* conv: as ydet_focus_conv3x3_nchw; iarg3 = image dtype */
+    YDET_OP_HEAD_DECODE = 10   /* conv + head: as ydet_head_conv_decode */
 } ydet_op_kind;
 
 typedef struct {
     int32_t kind;
     int32_t iarg, iarg2, iarg3;
-    ydet_conv_desc conv;   /* YDET_OP_CONV */
-    ydet_slice_desc slice; /* everything else */
+    ydet_conv_desc conv;   /* YDET_OP_CONV, YDET_OP_FOCUS_CONV, YDET_OP_HEAD_DECODE */
+    ydet_slice_desc slice; /* pooling / resampling / layout ops */
+    ydet_head_desc head;   /* YDET_OP_HEAD_DECODE */
 } ydet_op;
 
 int ydet_run_ops(const ydet_op* ops /* host */, int n_ops, void* stream);

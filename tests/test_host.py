@@ -137,15 +137,17 @@ def test_planner_v5s_on_cpu():
     m._lower(g, 2, 3, 640, 640)
     plan = g.finalize()
     kinds = [k for k, _ in g.ops]
-    assert kinds[0] == "focus_conv" and kinds.count("conv") == 53 and "copy" not in kinds   # 62 convolutions: 8 C3 (cv1, cv2)
+    assert kinds[0] == "focus_conv" and kinds.count("conv") == 50 and kinds.count("head_decode") == 3 and "copy" not in kinds   # 62 convolutions: 8 C3 (cv1, cv2)
     # pairs fused, the first one fused with the Focus slicing and the NCHW edge and kinds.count("spp") == 1 and kinds.count("upsample") == 2
     gflop = sum(i["flops"] for i in plan.op_info) / 2 / 1e9
     assert abs(gflop - 16.96) < 0.01          # conv FLOPs per 640x640 image of YOLOv5s
     g32 = engine.Graph("cpu", "fp32")      # the fp32 path keeps the layout kernel + a regular first convolution
     m._lower(g32, 2, 3, 640, 640)
     assert [k for k, _ in g32.ops][:2] == ["nchw2nhwc", "conv"]
-    heads = [op for op in plan.ops if op.kind == 0 and op.conv.out_dtype == 0]
+    heads = [op for op in plan.ops if op.kind == 10]     # prediction convs with the decode in their epilogue
     assert len(heads) == 3 and all(h.conv.Cout == 255 and h.conv.cout_store == 256 and h.conv.y_ld == 256 for h in heads)
+    assert [h.head.level_row_offset for h in heads] == [0, 19200, 24000] and heads[0].head.rows_per_image == 25200
+    assert set(g.outputs) == {"z", "row_max", "head0", "head1", "head2"}
 
 
 @pytest.mark.parametrize("tag,size,convs", [("v3tiny", 416, 13), ("v2d19", 416, 23), ("v3spp", 608, 75), ("v4", 608, 120)])

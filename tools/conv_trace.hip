@@ -6,6 +6,7 @@
 #include "../yolo_amd/csrc/conv.hip"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace ydet {
@@ -32,12 +33,26 @@ int main(int argc, char** argv) {
     d.x = x; d.w = w; d.bias = b; d.y = y;
     d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.KH = d.KW = k; d.stride = st; d.pad = pad; d.Ho = Ho; d.Wo = Wo;
     d.x_ld = Cin; d.y_ld = Cout; d.kp = kp; d.cout_pad = cout_pad; d.act = YDET_ACT_SILU; d.in_dtype = d.out_dtype = YDET_BF16;
+    // "head" as 8th argument: the prediction conv with the Detect decode in its epilogue (na = 3, no = Cout / 3)
+    const bool head = argc > 8 && !strcmp(argv[8], "head");
+    ydet_head_desc hd = {};
+    if (head) {
+        d.act = YDET_ACT_NONE; d.out_dtype = YDET_F32; d.cout_pad = 256; d.y_ld = 256; d.cout_store = 256;
+        CK(hipFree(w)); CK(hipMalloc(&w, (size_t)256 * kp * 2)); CK(hipMemset(w, 0x11, (size_t)256 * kp * 2)); d.w = w;
+        CK(hipFree(y)); CK(hipMalloc(&y, (size_t)N * Ho * Wo * 256 * 4)); d.y = y;
+        CK(hipFree(b)); CK(hipMalloc((void**)&b, 256 * 4)); CK(hipMemset(b, 0, 256 * 4)); d.bias = b;
+        hd.na = 3; hd.no = Cout / 3; hd.ny = Ho; hd.nx = Wo; hd.stride = 8.f; hd.rows_per_image = 3LL * Ho * Wo;
+        for (int i = 0; i < 6; ++i) hd.anchor_wh[i] = 10.f + i;
+        CK(hipMalloc((void**)&hd.z, (size_t)N * hd.rows_per_image * hd.no * 4));
+        CK(hipMalloc((void**)&hd.row_max, (size_t)N * hd.rows_per_image * 4));
+    }
+    auto launch = [&]() { return head ? ydet_launch_head_decode(&d, &hd, 0) : ydet_launch_conv(&d, 0); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) if (ydet_launch_conv(&d, 0)) return 1;
+    for (int i = 0; i < 3; ++i) if (launch()) return 1;
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     const int reps = 20;
-    for (int i = 0; i < reps; ++i) ydet_launch_conv(&d, 0);
+    for (int i = 0; i < reps; ++i) launch();
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("avg %.2f us per launch (%d back to back)\n", ms * 1e3 / reps, reps);

@@ -13,9 +13,9 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
- OP_NHWC2NCHW, OP_FOCUS_CONV) = range(10)
+ OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE) = range(11)
 MAX_ANCHORS = 8
-ABI_VERSION = 3   # YDET_ABI_VERSION of include/ydet.h these structs were written against
+ABI_VERSION = 4   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -58,10 +58,18 @@ class FALevel(C.Structure):
     ]
 
 
+class HeadDesc(C.Structure):
+    _fields_ = [
+        ("z", C.c_void_p), ("row_max", C.c_void_p), ("rows_per_image", C.c_int64), ("level_row_offset", C.c_int32),
+        ("na", C.c_int32), ("no", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32), ("grid_transposed", C.c_int32),
+        ("stride", C.c_float), ("anchor_wh", C.c_float * (2 * MAX_ANCHORS)),
+    ]
+
+
 class Op(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("iarg", C.c_int32), ("iarg2", C.c_int32), ("iarg3", C.c_int32),
-        ("conv", ConvDesc), ("slice", SliceDesc),
+        ("conv", ConvDesc), ("slice", SliceDesc), ("head", HeadDesc),
     ]
 
 
@@ -79,6 +87,7 @@ SYMBOLS = {
     "ydet_copy_slice_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
     "ydet_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "ydet_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "ydet_head_conv_decode": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(HeadDesc), C.c_void_p]),
     "ydet_decode_v5": (C.c_int, [C.POINTER(V5Level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "ydet_decode_v2v3": (C.c_int, [C.POINTER(FALevel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

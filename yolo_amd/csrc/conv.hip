@@ -60,6 +60,17 @@ struct ConvArgs {
     float post_slope;
 };
 
+// Detect decode of one pyramid level, done in the epilogue of its 1x1 prediction convolution (the tile holds all
+// na*no channels of its pixels).
+struct HeadArgs {
+    float* z;          // [N][rows_per_img][no]
+    float* row_max;    // [N][rows_per_img] or null
+    int na, no, hw, nx, ny, transposed, level_off;
+    long long rows_per_img;
+    float stride, rd;  // rd = 1/nx (1/ny when transposed)
+    float anchor[16];
+};
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int chunk_swz(int g) { return (0x78 >> (2 * (g & 3))) & 3; }
@@ -358,8 +369,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
-__global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const ConvArgs a) {
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool HEAD = false>
+__global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     constexpr int NW = WARPS_N * WARPS_M;         // waves per workgroup (4 or 8)
     constexpr int NT = 64 * NW;
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
@@ -396,7 +407,9 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     // dependent LDS store would put a cold global load's latency in front of the K loop) and parked behind the ring
     // right after the K loop, where the epilogue reads them
     YDET_STAMP(22);
-    float* cst = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
+    constexpr int HEAD_RP = BN + 4;   // floats per pixel row of the fp32 tile a decoding head stages in LDS
+    constexpr int CST_OFF = HEAD && BM * HEAD_RP * 4 > NSTAGE * STAGE ? BM * HEAD_RP * 4 : NSTAGE * STAGE;
+    float* cst = reinterpret_cast<float*>(smem + CST_OFF);
     float cst_b = 0.f, cst_ps = 0.f, cst_pb = 0.f;
     if (tid < BN) {
         if (a.bias) cst_b = a.bias[n0 + tid];
@@ -542,6 +555,179 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     }
     __syncthreads();   // constants visible; also: every wave is done with the ring
     const int q = lane >> 4, px = lane & 15;
+    if constexpr (HEAD) {
+        // LDS: fp32 tile [BM][HEAD_RP] at 0 (first the raw values, then their sigmoids), per-pixel records behind the
+        // per-channel constants
+        float* stage = reinterpret_cast<float*>(smem);
+        int* pix_row = reinterpret_cast<int*>(cst + 3 * BN);        // first z row of the pixel (anchor 0), -1: no pixel
+        float* pix_gx = reinterpret_cast<float*>(pix_row + BM);
+        float* pix_gy = pix_gx + BM;
+        float* anc = pix_gy + BM;                                     // anchor (w, h) pairs of the level
+        if (tid < BM) {
+            const long long m = m0 + tid;
+            int row = -1;
+            float gx = 0.f, gy = 0.f;
+            if (m < a.M) {
+                const int n = (int)((unsigned)m / (unsigned)h.hw);
+                const int cell = (int)((unsigned)m - (unsigned)n * (unsigned)h.hw);
+                const int d = h.transposed ? h.ny : h.nx;
+                const int qd = div_small(cell, d, h.rd), rem = cell - qd * d;
+                // grid offset of the cell: (col, row), or with the transposed table flat cell f holds (f / ny, f % ny)
+                gx = h.transposed ? (float)qd : (float)rem;
+                gy = h.transposed ? (float)rem : (float)qd;
+                row = (int)((long long)n * h.rows_per_img + h.level_off + cell);
+            }
+            pix_row[tid] = row; pix_gx[tid] = gx; pix_gy[tid] = gy;
+        }
+        // (1) accumulators + bias -> tile, pixel-major
+        auto stage_tile = [&](auto squash) {
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int pl = wm * WM + j * 16 + px;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const int cl = wn * WN + i * 16 + q * 4;
+                    const float4 b = *reinterpret_cast<const float4*>(cst + cl);
+                    float4 v = make_float4(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
+                    if (decltype(squash)::value)
+                        v = make_float4(sigmoid_fast(v.x), sigmoid_fast(v.y), sigmoid_fast(v.z), sigmoid_fast(v.w));
+                    *reinterpret_cast<float4*>(stage + pl * HEAD_RP + cl) = v;
+                }
+            }
+        };
+        YDET_STAMP(20);
+        stage_tile(std::false_type{});
+        __syncthreads();
+        YDET_STAMP(21);
+        // (2) the raw prediction map, whole 16-byte pieces
+        constexpr int PIECES = BN / 4;
+        static_assert(BM * PIECES % NT == 0, "whole pieces per thread");
+        {
+            float4 piece_v[BM * PIECES / NT];
+#pragma unroll
+            for (int k = 0; k < BM * PIECES / NT; ++k) {      // all LDS reads first, then the stores
+                const int idx = tid + k * NT;
+                piece_v[k] = *reinterpret_cast<const float4*>(stage + (idx / PIECES) * HEAD_RP + (idx % PIECES) * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < BM * PIECES / NT; ++k) {
+                const int idx = tid + k * NT;
+                const int pl = idx / PIECES, piece = idx % PIECES;
+                const long long m = m0 + pl;
+                const int co = n0 + piece * 4;
+#ifdef YDET_EXP_NO_RAWST
+                if (m < a.M && co < a.cout_store && piece_v[k].x == 12345.678f)
+#else
+                if (m < a.M && co < a.cout_store)
+#endif
+                    *reinterpret_cast<float4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(float)) = piece_v[k];
+            }
+        }
+        __syncthreads();
+        YDET_STAMP(22);
+        // (3) sigmoid of every value, taken where the tile sits in registers with all lanes busy, and laid down in the
+        // order of the decoded rows: zt[anchor][pixel][column], so each anchor's part of the tile is one run of z
+        float* zt = stage;
+        const int per_an = BM * h.no;                                // floats per anchor
+        {
+            const float rno = 1.0f / (float)h.no;
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int pl = wm * WM + j * 16 + px;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const int cl = wn * WN + i * 16 + q * 4;
+                    const float4 b = *reinterpret_cast<const float4*>(cst + cl);
+                    const float v[4] = {sigmoid_fast(acc[i][j][0] + b.x), sigmoid_fast(acc[i][j][1] + b.y),
+                                        sigmoid_fast(acc[i][j][2] + b.z), sigmoid_fast(acc[i][j][3] + b.w)};
+                    int an = div_small(cl, h.no, rno), o = cl - an * h.no;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (an < h.na) zt[an * per_an + pl * h.no + o] = v[e];
+                        const bool wrap = o + 1 == h.no;
+                        o = wrap ? 0 : o + 1;
+                        an += wrap ? 1 : 0;
+                    }
+                }
+            }
+        }
+        if (tid < 16) anc[tid] = h.anchor[tid];
+        __syncthreads();
+        YDET_STAMP(23);
+        // (4) decode (yolov5_official/model.py:56-81).  Row maxima: one thread per (pixel, anchor) walks the classes.
+        for (int item = tid; item < BM * h.na; item += NT) {
+            const int an = item / BM, pl = item - an * BM;
+            const int row = pix_row[pl];
+            float* src = zt + an * per_an + pl * h.no;
+            const float4 s4 = make_float4(src[0], src[1], src[2], src[3]);
+            if (h.row_max && row >= 0) {
+                const float obj = src[4];
+                float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // independent chains: reads overlap
+                int c = 5;
+                for (; c + 8 <= h.no; c += 8) {
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = src[c + e];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mx[e & 3] = fmaxf(mx[e & 3], t[e] * obj);
+                }
+                for (; c < h.no; ++c) mx[0] = fmaxf(mx[0], src[c] * obj);
+                h.row_max[(long long)row + (long long)an * h.hw] = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+            }
+            // the box: centre from the cell offset and the stride, size from the anchor
+            const float tx = s4.x * 2.0f, ty = s4.y * 2.0f, tw = s4.z * 2.0f, th = s4.w * 2.0f;
+            src[0] = (tx - 0.5f + pix_gx[pl]) * h.stride;
+            src[1] = (ty - 0.5f + pix_gy[pl]) * h.stride;
+            src[2] = tw * tw * anc[2 * an];
+            src[3] = th * th * anc[2 * an + 1];
+        }
+        __syncthreads();
+        YDET_STAMP(24);
+        // z: when the tile's pixels are consecutive rows of one image, each anchor's part is one run of BM*no floats in
+        // z as well, and the tile goes out as whole 16-byte pieces
+        {
+            const int row0 = pix_row[0];
+            const bool run = row0 >= 0 && pix_row[BM - 1] == row0 + BM - 1;
+            const long long z0 = (long long)row0 * h.no;                       // first float of anchor 0's run
+            const int an_step = h.hw * h.no;                                   // floats between anchors (< 2^31 checked)
+            const bool vec = run && (z0 & 3) == 0 && (an_step & 3) == 0 && ((size_t)h.z & 15) == 0;
+            if (vec) {
+                const int per4 = per_an / 4, total4 = per4 * h.na;
+                const float rper4 = 1.0f / (float)per4;
+                float* zb = h.z + z0;
+                constexpr int ZU = 8;
+                for (int k0 = tid; k0 < total4; k0 += NT * ZU) {
+                    float4 v[ZU];
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) {
+                        const int k = k0 + u * NT;
+                        if (k < total4) v[u] = *reinterpret_cast<const float4*>(zt + 4 * k);
+                    }
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) {
+                        const int k = k0 + u * NT;
+                        if (k < total4) {
+#ifdef YDET_EXP_NO_ZST
+                            if (v[u].x != 12345.678f) continue;
+#endif
+                            const int an = div_small(k, per4, rper4);
+                            *reinterpret_cast<float4*>(zb + (size_t)(unsigned)(an * an_step + (k - an * per4) * 4)) = v[u];
+                        }
+                    }
+                }
+            } else {
+                const float rno = 1.0f / (float)h.no;
+                for (int an = 0; an < h.na; ++an)
+                    for (int f = tid; f < per_an; f += NT) {
+                        const int pl = div_small(f, h.no, rno), o = f - pl * h.no;
+                        const int row = pix_row[pl];
+                        if (row >= 0) h.z[((long long)row + (long long)an * h.hw) * h.no + o] = zt[an * per_an + f];
+                    }
+            }
+        }
+        YDET_STAMP(25);
+        return;
+    }
     with_epilogue_mode(a, [&](auto mode) {
         constexpr int MODE = decltype(mode)::value;
         if (a.lds_epilogue) {
@@ -631,12 +817,12 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
                              : 0;
         if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
             static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M>),
+                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float)));
             if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         }
-        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M>), dim3((unsigned)nblk), dim3(64 * NW),
-                           lds_dma, stream, a);
+        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
+                           dim3(64 * NW), lds_dma, stream, a, HeadArgs{});
         YDET_CHECK_LAUNCH("conv_dma_kernel");
         return YDET_OK;
     }
@@ -696,7 +882,7 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
+static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     YDET_CHECK_ARG(d != nullptr, "conv: null descriptor");
     YDET_CHECK_ARG(d->x && d->w && d->y, "conv: null x/w/y pointer");
     YDET_CHECK_ARG(dtype_ok(d->in_dtype) && dtype_ok(d->out_dtype), "conv: bad dtype %d/%d", d->in_dtype,
@@ -731,7 +917,6 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
     YDET_CHECK_ARG((long long)d->H * d->W * d->x_ld < (1LL << 31), "conv: one image exceeds 2^31 elements");
     YDET_CHECK_ARG((long long)d->N * d->Ho * d->Wo < (1LL << 31), "conv: more than 2^31 output pixels");
 
-    ConvArgs a;
     a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.res = (const char*)d->res;
     a.y = (char*)d->y;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
@@ -749,11 +934,72 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
                    (!d->res || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0)))
                       ? 1
                       : 0;
+    return YDET_OK;
+}
 
+int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
+    ConvArgs a;
+    const int rc = fill_conv_args(d, a);
+    if (rc != YDET_OK) return rc;
     if (d->in_dtype == YDET_BF16)
         return d->out_dtype == YDET_BF16 ? launch_dtype<__bf16, __bf16>(a, stream)
                                          : launch_dtype<__bf16, float>(a, stream);
     return launch_dtype<float, float>(a, stream);
+}
+
+// 1x1 prediction convolution of one pyramid level + Detect decode in its epilogue: 256-channel x 64-pixel tiles, so a
+// workgroup owns every channel of its pixels.
+template <typename TIN>
+static int launch_head(const ConvArgs& a0, const HeadArgs& h, hipStream_t stream) {
+    constexpr int BN = 256, BM = 64, BK = 64 / (int)sizeof(TIN);
+    ConvArgs a = a0;
+    a.tiles_n = 1;
+    const long long nblk = (a.M + BM - 1) / BM;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(YDET_ERR_ARG, "head_conv_decode: grid of %lld blocks", nblk);
+    (void)BK;
+    const int ring = 3 * (BN + BM) * 64, tile = BM * (BN + 4) * 4;
+    const int lds = (tile > ring ? tile : ring) + 3 * BN * (int)sizeof(float) + 3 * BM * 4 + 16 * 4;
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv_dma_kernel<TIN, float, BN, BM, 4, 1, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "head_conv_decode: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL((conv_dma_kernel<TIN, float, BN, BM, 4, 1, true>), dim3((unsigned)nblk), dim3(256), lds, stream, a, h);
+    YDET_CHECK_LAUNCH("conv_dma_kernel<head>");
+    return YDET_OK;
+}
+
+int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, hipStream_t stream) {
+    ConvArgs a;
+    const int rc = fill_conv_args(d, a);
+    if (rc != YDET_OK) return rc;
+    YDET_CHECK_ARG(hd != nullptr && hd->z != nullptr, "head_conv_decode: null head descriptor / z");
+    const int bk = d->in_dtype == YDET_BF16 ? 32 : 16;
+    YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % bk == 0,
+                   "head_conv_decode: a 1x1 convolution with Cin a multiple of %d", bk);
+    YDET_CHECK_ARG(d->out_dtype == YDET_F32 && d->act == YDET_ACT_NONE && d->res == nullptr && d->post_scale == nullptr,
+                   "head_conv_decode: plain fp32 prediction map expected");
+    YDET_CHECK_ARG(hd->na >= 1 && hd->na <= 8 && hd->no >= 5 && hd->no <= 128 && hd->na * hd->no == d->Cout && d->Cout <= 256,
+                   "head_conv_decode: na=%d no=%d Cout=%d (na*no = Cout <= 256, no <= 128)", hd->na, hd->no, d->Cout);
+    YDET_CHECK_ARG(d->cout_pad >= 256 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0 && a.cout_store % 4 == 0,
+                   "head_conv_decode: weights padded to 256 rows and a 4-aligned output slice");
+    YDET_CHECK_ARG(hd->ny == d->Ho && hd->nx == d->Wo && (long long)hd->ny * hd->nx < (1 << 22) &&
+                       (long long)hd->ny * hd->nx * d->Cout < (1ll << 31), "head_conv_decode: map size");
+    YDET_CHECK_ARG(hd->rows_per_image >= (long long)hd->level_row_offset + (long long)hd->na * hd->ny * hd->nx &&
+                       hd->level_row_offset >= 0, "head_conv_decode: level rows exceed rows_per_image");
+    HeadArgs h;
+    h.z = hd->z; h.row_max = hd->row_max;
+    h.na = hd->na; h.no = hd->no; h.ny = hd->ny; h.nx = hd->nx; h.hw = hd->ny * hd->nx;
+    h.transposed = hd->grid_transposed ? 1 : 0;
+    h.level_off = hd->level_row_offset; h.rows_per_img = hd->rows_per_image;
+    h.stride = hd->stride;
+    h.rd = 1.0f / (float)(h.transposed ? hd->ny : hd->nx);
+    for (int i = 0; i < 16; ++i) h.anchor[i] = i < 2 * hd->na ? hd->anchor_wh[i] : 0.f;
+    return d->in_dtype == YDET_BF16 ? launch_head<__bf16>(a, h, stream) : launch_head<float>(a, h, stream);
+}
+
+extern "C" int ydet_head_conv_decode(const ydet_conv_desc* d, const ydet_head_desc* head, void* stream) {
+    clear_error();
+    return ydet_launch_head_decode(d, head, as_stream(stream));
 }
 
 extern "C" int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream) {

@@ -1,8 +1,6 @@
 // Box decode kernels (gfx950).  Both are HBM-bound: every head value is read once and every decoded
 // value written once.  Compiled with -ffp-contract=off so that the arithmetic keeps the operation
 // order of the Python expressions it replaces.
-#include <type_traits>
-
 #include "ydet_internal.h"
 
 using namespace ydet;
@@ -13,30 +11,6 @@ constexpr int kMaxLevels = 4;
 constexpr int kMaxAnchors = 8;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-// hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32): relative error below 1e-6 for |x| < 16, absolute error below
-// 1e-8 beyond; about 5 instructions instead of 25
-__device__ __forceinline__ float sigmoid_fast(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
-}
-
-// max over the 64 lanes of a wave, returned in every lane: four DPP steps inside each row of 16 lanes, then the
-// four row results are combined as scalars.
-__device__ __forceinline__ float wave_max(float v) {
-    auto step = [](float x, auto ctrl) {
-        const int y = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false);
-        return fmaxf(x, __int_as_float(y));
-    };
-    v = step(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-    v = step(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-    v = step(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-    v = step(v, std::integral_constant<int, 0x140>{});   // row_mirror
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-
 // --------------------------------------------------------------------------------------------------
 // YOLOv5 Detect decode.
 // --------------------------------------------------------------------------------------------------
@@ -50,15 +24,6 @@ struct V5LevelArgs {   // one launch per pyramid level
     float stride, rd;   // rd = 1/nx (1/ny when transposed)
     float anchor[2 * kMaxAnchors];
 };
-
-// x / d for 0 <= x < 2^22, 0 < d, given rd = 1.0f / d: the float product is off by less than one.
-__device__ __forceinline__ int div_small(int x, int d, float rd) {
-    int q = (int)((float)x * rd);
-    const int r = x - q * d;
-    if (r < 0) --q;
-    else if (r >= d) ++q;
-    return q;
-}
 
 // One wave decodes whole pixels, anchor by anchor: the `no` channels of one (pixel, anchor) are contiguous in the
 // NHWC head map and form one contiguous output row, lane l holds columns l, l+64, ... (OR registers cover

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "ydet.h"
 
 namespace ydet {
@@ -49,10 +51,45 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + local;
 }
 
+// ---- pieces shared by the Detect decode kernel and the head convolution that decodes in its epilogue --------------
+// hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32): relative error below 1e-6 for |x| < 16, absolute error below
+// 1e-8 beyond; about 5 instructions instead of 25
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
+// max over the 64 lanes of a wave, returned in every lane: four DPP steps inside each row of 16 lanes, then the
+// four row results are combined as scalars.
+__device__ __forceinline__ float wave_max(float v) {
+    auto step = [](float x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false);
+        return fmaxf(x, __int_as_float(y));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// x / d for 0 <= x < 2^22, 0 < d, given rd = 1.0f / d: the float product is off by less than one.
+__device__ __forceinline__ int div_small(int x, int d, float rd) {
+    int q = (int)((float)x * rd);
+    const int r = x - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace ydet
 
 // Internal launchers shared by the public entry points and ydet_run_ops.
 int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream);
+int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, hipStream_t stream);
 int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream);

@@ -222,6 +222,24 @@ class Graph:
                                       res_mode=res_mode if res is not None else _ffi.RES_NONE, post=post_rec)))
         return out
 
+    def head_decode(self, x, conv, z, row_max, level_off, na, no, stride, anchors, transposed):
+        """1x1 prediction conv of one Detect level with the decode in its epilogue.  z / row_max: external storages
+        [N,1,rows,no] / [N,1,rows,1] shared by the levels; returns the raw fp32 head map (external, 256-padded)."""
+        pc = pack_conv(conv, None, None, cin_phys=x.C, dtype=self.dt, device=self.device)
+        if pc.cout_pad < 256:      # the kernel's weight tile is 256 rows
+            wp = torch.zeros(256, pc.kp, device=self.device, dtype=pc.w.dtype)
+            wp[:pc.cout_pad] = pc.w
+            bp = torch.zeros(256, device=self.device)
+            bp[:pc.cout_pad] = pc.b
+            pc = PackedConv(wp, bp, pc.Cin, pc.Cout, pc.KH, pc.KW, pc.kp, 256, cin_real=pc.cin_real)
+        self.keep.append(pc)
+        out = self.new(x.N, x.H, x.W, pc.Cout, dtype=_ffi.F32, external=True)
+        self.ops.append(("head_decode", dict(x=x, y=out, res=None, pc=pc, stride=1, pad=0, act=_ffi.ACT_NONE, slope=0.0,
+                                             res_mode=_ffi.RES_NONE, post=None, z=z, row_max=row_max, level_off=level_off,
+                                             na=na, no=no, det_stride=float(stride), anchors=[float(v) for v in anchors],
+                                             transposed=int(bool(transposed)))))
+        return out
+
     def _slice_op(self, kind, x, out, iarg=0):
         self.ops.append((kind, dict(x=x, y=out, iarg=iarg)))
         return out
@@ -325,6 +343,20 @@ class Plan:
     def _fill(self, op, i, kind, a, arena, record):
         if kind == "conv":
             self._fill_conv(op, i, a, arena, record)
+        elif kind == "head_decode":
+            self._fill_conv(op, i, a, arena, record)
+            op.kind = _ffi.OP_HEAD_DECODE
+            hd = op.head
+            zroot, _ = a["z"].resolve()
+            hd.z = self._ptr(zroot, arena, i, "hz", record)
+            if a["row_max"] is not None:
+                rroot, _ = a["row_max"].resolve()
+                hd.row_max = self._ptr(rroot, arena, i, "hr", record)
+            hd.rows_per_image, hd.level_row_offset = zroot.W, a["level_off"]
+            hd.na, hd.no, hd.ny, hd.nx = a["na"], a["no"], a["y"].H, a["y"].W
+            hd.grid_transposed, hd.stride = a["transposed"], a["det_stride"]
+            for k, v in enumerate(a["anchors"]):
+                hd.anchor_wh[k] = v
         elif kind == "focus_conv":
             op.kind = _ffi.OP_FOCUS_CONV
             d, pc = op.conv, a["pc"]
@@ -443,6 +475,10 @@ class Plan:
                     op.conv.x = ptr
                 elif field == "cy":
                     op.conv.y = ptr
+                elif field == "hz":
+                    op.head.z = ptr
+                elif field == "hr":
+                    op.head.row_max = ptr
                 else:
                     op.conv.res = ptr
         for i, name, shape, dt in self.nchw_out:
@@ -527,6 +563,13 @@ def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0):
 
 def _op_info(kind, a):
     esz = lambda t: 2 if t.dtype == _ffi.BF16 else 4
+    if kind == "head_decode":
+        x, y, pc = a["x"], a["y"], a["pc"]
+        flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.cin_real
+        nbytes = (x.N * x.H * x.W * x.C * esz(x) + pc.Cout * x.C * esz(x) + y.N * y.H * y.W * 256 * 4
+                  + y.N * y.H * y.W * pc.Cout * 4)
+        return dict(kind="conv", label="conv_head_decode", flops=flops, bytes=nbytes,
+                    shape=(x.N, x.H, x.W, x.C, pc.Cout, 1, 1))
     if kind == "conv":
         x, y, pc = a["x"], a["y"], a["pc"]
         flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.cin_real * pc.KH * pc.KW

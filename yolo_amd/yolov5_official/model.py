@@ -77,23 +77,56 @@ class Detect(nn.Module):
 
     # ---- HIP face --------------------------------------------------------------------------------
     def lower(self, g, xs):
-        """Emit the three bias-only 1x1 head convs; outputs are fp32 NHWC buffers handed to the caller."""
+        """Emit the bias-only 1x1 head convs; outputs are fp32 NHWC buffers handed to the caller.  When the head fits
+        the fused kernel (na*no <= 256, no <= 128, input channels a multiple of the K step) every level is ONE launch
+        that also decodes: the plan then has the outputs "z" and "row_max" next to "head{i}"."""
+        bk = 32 if g.dt == _ffi.BF16 else 16
+        fused = (self.na * self.no <= 256 and self.no <= 128 and self.no > 5 and self.na <= 8
+                 and all(x.C % bk == 0 and m.kernel_size == (1, 1) for x, m in zip(xs, self.m)))
         heads = []
-        for i, x in enumerate(xs):
-            heads.append(g.conv(x, self.m[i], out_dtype=_ffi.F32, external=True))
-            g.output(f"head{i}", heads[-1])
+        if fused:
+            rows = sum(self.na * x.H * x.W for x in xs)
+            z = g.new(xs[0].N, 1, rows, self.no, dtype=_ffi.F32, external=True, ld=self.no)
+            rm = g.new(xs[0].N, 1, rows, 1, dtype=_ffi.F32, external=True, ld=1)
+            strides, anchors = self._host_constants()
+            off = 0
+            for i, x in enumerate(xs):
+                heads.append(g.head_decode(x, self.m[i], z, rm, off, self.na, self.no, strides[i], anchors[i],
+                                           self.grid_transposed))
+                off += self.na * x.H * x.W
+            g.output("z", z)
+            g.output("row_max", rm)
+        else:
+            for i, x in enumerate(xs):
+                heads.append(g.conv(x, self.m[i], out_dtype=_ffi.F32, external=True))
+        for i, h in enumerate(heads):
+            g.output(f"head{i}", h)
         return heads
 
-    def decode(self, heads):
-        """heads: NHWC fp32 maps [N, ny, nx, na*no] -> (z, [x_i]) as the reference returns them."""
-        # host copies of stride / anchor_grid, refreshed when the buffer changes (reading them from the device
-        # on every call would stall the stream)
+    def _host_constants(self):
+        """Host copies of stride / anchor_grid, refreshed when the buffer changes (reading them from the device on
+        every call would stall the stream)."""
         ver = (self.anchor_grid._version, self.anchor_grid.data_ptr(), tuple(float(s) for s in self.stride))
         cached = self.__dict__.get("_ydet_anchor_host")
         if cached is None or cached[0] != ver:
             cached = (ver, self.anchor_grid.detach().float().cpu().view(self.nl, -1).tolist())
             self.__dict__["_ydet_anchor_host"] = cached
-        strides, anchors = list(ver[2]), cached[1]
+        return list(ver[2]), cached[1]
+
+    def finish(self, outs):
+        """Plan outputs -> (z, [x_i]) as the reference returns them: the decoded tensor comes from the fused head
+        kernels when the plan has it, from the stand-alone decode kernel otherwise."""
+        heads = [outs[f"head{i}"] for i in range(self.nl)]
+        if "z" not in outs:
+            return self.decode(heads)
+        z = outs["z"].view(heads[0].shape[0], -1, self.no)
+        z._ydet_row_max = (outs["row_max"].view(z.shape[0], -1), z._version)
+        xs = [h.view(h.shape[0], h.shape[1], h.shape[2], self.na, self.no).permute(0, 3, 1, 2, 4) for h in heads]
+        return z, xs
+
+    def decode(self, heads):
+        """heads: NHWC fp32 maps [N, ny, nx, na*no] -> (z, [x_i]) as the reference returns them."""
+        strides, anchors = self._host_constants()
         z = ops.decode_v5(heads, strides, anchors, self.na, self.no, self.grid_transposed)
         xs = [h.view(h.shape[0], h.shape[1], h.shape[2], self.na, self.no).permute(0, 3, 1, 2, 4) for h in heads]
         return z, xs
@@ -109,7 +142,7 @@ class Detect(nn.Module):
             return g.finalize()
 
         outs = cache.get(key, build).run(*x)
-        z, xs = self.decode([outs[f"head{i}"] for i in range(self.nl)])
+        z, xs = self.finish(outs)
         for i in range(self.nl):
             x[i] = xs[i]
         return z, x
@@ -336,7 +369,7 @@ class Model(engine.AcceleratedModule):
             return engine.build_plan(x.device, compute, x.shape[0], lambda g, n: self._lower(g, n, *x.shape[1:]))
 
         outs = self._plans().get(key, build).run(x)
-        z, xs = det.decode([outs[f"head{i}"] for i in range(det.nl)])
+        z, xs = det.finish(outs)
         p = next(self.parameters())
         if p.dtype != torch.float32:  # model.half(): hand back tensors in the model's dtype
             z, xs = z.to(p.dtype), [t.to(p.dtype) for t in xs]
