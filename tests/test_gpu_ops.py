@@ -405,3 +405,57 @@ def test_focus_stem_fused(shape, cout, src):
     assert outs["bf16"].shape == ref.shape
     assert rel_err(outs["fp32"], ref) < (1e-3 if src == torch.float32 else 1e-2)
     assert rel_err(outs["bf16"], ref) < 2e-2
+
+
+# ---- 32-channel bottleneck as one kernel ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 32, 16, 64), (1, 32, 13, 37), (3, 32, 40, 40), (1, 32, 5, 3)])
+@pytest.mark.parametrize("add", [True, False])
+@pytest.mark.parametrize("act", ["silu", "leaky"])
+def test_bottleneck_c32_fused(shape, add, act):
+    """Tile-aligned and ragged maps (8 x 32 output tiles), with and without the shortcut: the fused kernel against
+    torch fp32 (bf16 bar) and against the same two stages run as separate convolutions (same bf16 intermediate and
+    accumulation order; the epilogues may contract multiply-adds differently, so the bar is one bf16 ulp)."""
+    from yolo_amd.yolov5_official.modules import Bottleneck
+    from yolo_amd.synthetic import init_deterministic
+    m = Bottleneck(32, 32, shortcut=add, e=1.0)
+    if act == "leaky":
+        m.cv1.act = m.cv2.act = nn.LeakyReLU(0.1)
+    init_deterministic(m, seed=5)
+    m.eval()
+    x = torch.randn(*shape, generator=_gen(9, f"bneck{shape}")).bfloat16().float()
+    with torch.no_grad():
+        ref = m(x)
+    m = m.to(DEV)
+    code, slope = (_ffi.ACT_SILU, 0.0) if act == "silu" else (_ffi.ACT_LEAKY, 0.1)
+
+    def fused(gr, ins):
+        y = m.lower(gr, ins[0])
+        assert [k for k, _ in gr.ops][-1] == "bottleneck"
+        gr.to_nchw(y, "y")
+
+    def split(gr, ins):
+        t = gr.conv(ins[0], m.cv1.conv, m.cv1.bn, act=code, slope=slope)
+        y = gr.conv(t, m.cv2.conv, m.cv2.bn, act=code, slope=slope, res=ins[0] if add else None, res_mode=_ffi.RES_AFTER_ACT)
+        gr.to_nchw(y, "y")
+
+    a = _run_graph(fused, x, compute="bf16")["y"].float().cpu()
+    b = _run_graph(split, x, compute="bf16")["y"].float().cpu()
+    assert a.shape == ref.shape
+    assert rel_err(a, ref) < 2e-2
+    assert rel_err(a, b) < 2.0 ** -8
+    assert (a != b).float().mean() < 0.02
+
+
+def test_bottleneck_c32_rejects_in_place():
+    lib = _ffi.lib()
+    buf = torch.zeros(1, 8, 8, 32, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(128, 288, device=DEV, dtype=torch.bfloat16)
+    b = torch.zeros(128, device=DEV)
+    c1, c2 = _ffi.ConvDesc(), _ffi.ConvDesc()
+    for d, k, p, kp in ((c1, 1, 0, 32), (c2, 3, 1, 288)):
+        d.x = d.y = buf.data_ptr()
+        d.w, d.bias = w.data_ptr(), b.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = 1, 8, 8, 32, 32, k, k, 1, p, 8, 8
+        d.x_ld = d.y_ld = 32
+        d.kp, d.cout_pad, d.act, d.in_dtype, d.out_dtype = kp, 128, _ffi.ACT_SILU, _ffi.BF16, _ffi.BF16
+    assert lib.ydet_bottleneck_c32(c1, c2, None) == -1 and b"overlaps" in lib.ydet_last_error()

@@ -137,8 +137,13 @@ def test_planner_v5s_on_cpu():
     m._lower(g, 2, 3, 640, 640)
     plan = g.finalize()
     kinds = [k for k, _ in g.ops]
-    assert kinds[0] == "focus_conv" and kinds.count("conv") == 50 and kinds.count("head_decode") == 3 and "copy" not in kinds   # 62 convolutions: 8 C3 (cv1, cv2)
-    # pairs fused, the first one fused with the Focus slicing and the NCHW edge and kinds.count("spp") == 1 and kinds.count("upsample") == 2
+    # 62 convolutions: 8 C3 (cv1, cv2) pairs fused, the first one fused with the Focus slicing and the NCHW edge, the
+    # 32-channel bottleneck of the first C3 (1x1 + 3x3) one kernel, the three prediction convs decode in place
+    assert kinds[0] == "focus_conv" and kinds.count("conv") == 48 and kinds.count("bottleneck") == 1
+    assert kinds.count("head_decode") == 3 and "copy" not in kinds
+    assert kinds.count("spp") == 1 and kinds.count("upsample") == 2
+    bn = [op for op in plan.ops if op.kind == 11][0]          # reads the back slot, writes the front slot of a 96-wide buffer
+    assert (bn.conv.x_ld, bn.conv.x_coff, bn.conv2.y_ld, bn.conv2.y_coff, bn.conv2.res_coff) == (96, 64, 96, 0, 64)
     gflop = sum(i["flops"] for i in plan.op_info) / 2 / 1e9
     assert abs(gflop - 16.96) < 0.01          # conv FLOPs per 640x640 image of YOLOv5s
     g32 = engine.Graph("cpu", "fp32")      # the fp32 path keeps the layout kernel + a regular first convolution

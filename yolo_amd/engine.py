@@ -168,10 +168,16 @@ class Graph:
         return out
 
     # ---- operators -----------------------------------------------------------------------------
-    def conv_siblings(self, x, pairs, act=_ffi.ACT_NONE, slope=0.0):
+    def slice(self, t, off, C):
+        """Channels [off, off + C) of `t`."""
+        assert 0 <= off and off + C <= t.C
+        return T(t.st, t.coff + off, C)
+
+    def conv_siblings(self, x, pairs, act=_ffi.ACT_NONE, slope=0.0, lead=0, tail=0):
         """Several (conv, bn) pairs that read the same input with the same geometry and activation, run as ONE
         convolution whose output channels are the pairs' outputs side by side (the input is read once).
-        Returns the list of channel slices, in order; they share one storage."""
+        Returns (buffer, list of the pairs' channel slices in order); they share one storage, which has `lead`
+        free channels in front of the outputs and `tail` behind them."""
         folded = [fold_conv(c, b, None, self.device) for c, b in pairs]
         first = pairs[0][0]
         for c, _ in pairs[1:]:
@@ -182,10 +188,10 @@ class Graph:
         s, p = first.stride[0], first.padding[0]
         Ho = (x.H + 2 * p - pc.KH) // s + 1
         Wo = (x.W + 2 * p - pc.KW) // s + 1
-        out = self.new(x.N, Ho, Wo, pc.Cout)
-        self.ops.append(("conv", dict(x=x, y=out, res=None, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
-                                      res_mode=_ffi.RES_NONE, post=None)))
-        parts, off = [], 0
+        out = self.new(x.N, Ho, Wo, lead + pc.Cout + tail)
+        self.ops.append(("conv", dict(x=x, y=T(out.st, lead, pc.Cout), res=None, pc=pc, stride=s, pad=p, act=act,
+                                      slope=float(slope), res_mode=_ffi.RES_NONE, post=None)))
+        parts, off = [], lead
         for w, _ in folded:
             parts.append(T(out.st, off, w.shape[0]))
             off += w.shape[0]
@@ -220,6 +226,33 @@ class Graph:
             assert (res.N, res.H, res.W, res.C) == (out.N, out.H, out.W, out.C), "residual shape mismatch"
         self.ops.append(("conv", dict(x=x, y=out, res=res, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
                                       res_mode=res_mode if res is not None else _ffi.RES_NONE, post=post_rec)))
+        return out
+
+    def bottleneck(self, x, cv1, cv2, act=_ffi.ACT_NONE, slope=0.0, add=True, out=None):
+        """x + cv2(cv1(x)) (or cv2(cv1(x)) without `add`) for cv1 = (1x1 conv, bn), cv2 = (3x3 conv, bn) sharing one
+        activation.  One fused kernel when every channel count is 32 on the bf16 path and `out` does not alias `x`
+        (the intermediate map then never exists in HBM); otherwise two convolutions."""
+        (c1, bn1), (c2, bn2) = cv1, cv2
+        geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups)
+        fused = (self.dt == _ffi.BF16 and x.C == 32 and c1.out_channels == 32 and c2.out_channels == 32
+                 and geom(c1) == (1, 1, 0, 1) and geom(c2) == (3, 1, 1, 1) and x.dtype == _ffi.BF16
+                 and (out is None or out.resolve()[0] is not x.resolve()[0] or out.resolve()[1] + 32 <= x.resolve()[1]
+                      or x.resolve()[1] + 32 <= out.resolve()[1]))
+        if not fused:
+            t = self.conv(x, c1, bn1, act=act, slope=slope)
+            return self.conv(t, c2, bn2, act=act, slope=slope, res=x if add else None, res_mode=_ffi.RES_AFTER_ACT, out=out)
+        pc1 = pack_conv(c1, bn1, None, cin_phys=32, dtype=self.dt, device=self.device)
+        pc2 = pack_conv(c2, bn2, None, cin_phys=32, dtype=self.dt, device=self.device)
+        self.keep += [pc1, pc2]
+        if out is None:
+            out = self.new(x.N, x.H, x.W, 32)
+        assert (out.N, out.H, out.W, out.C, out.dtype) == (x.N, x.H, x.W, 32, _ffi.BF16), "bottleneck output shape mismatch"
+        common = dict(x=x, y=out, act=act, slope=float(slope), post=None)
+        self.ops.append(("bottleneck", dict(
+            x=x, y=out, add=bool(add), pc=pc1, pc2=pc2,
+            cv1=dict(common, res=None, pc=pc1, stride=1, pad=0, res_mode=_ffi.RES_NONE),
+            cv2=dict(common, res=x if add else None, pc=pc2, stride=1, pad=1,
+                     res_mode=_ffi.RES_AFTER_ACT if add else _ffi.RES_NONE))))
         return out
 
     def head_decode(self, x, conv, z, row_max, level_off, na, no, stride, anchors, transposed):
@@ -343,6 +376,11 @@ class Plan:
     def _fill(self, op, i, kind, a, arena, record):
         if kind == "conv":
             self._fill_conv(op, i, a, arena, record)
+        elif kind == "bottleneck":
+            assert not a["x"].resolve()[0].external and not a["y"].resolve()[0].external
+            self._fill_conv(op, i, a["cv1"], arena, record)
+            self._fill_conv(op, i, a["cv2"], arena, record, d=op.conv2)
+            op.kind = _ffi.OP_BOTTLENECK_C32
         elif kind == "head_decode":
             self._fill_conv(op, i, a, arena, record)
             op.kind = _ffi.OP_HEAD_DECODE
@@ -401,9 +439,9 @@ class Plan:
             sl.N, sl.H, sl.W, sl.C = x.N, x.H, x.W, x.C
             sl.x_ld, sl.x_coff, sl.y_ld, sl.y_coff, sl.dtype = rx.ld, ox, ry.ld, oy, rx.dtype
 
-    def _fill_conv(self, op, i, a, arena, record):
+    def _fill_conv(self, op, i, a, arena, record, d=None):
         op.kind = _ffi.OP_CONV
-        d = op.conv
+        d = op.conv if d is None else d
         x, y, res, pc = a["x"], a["y"], a["res"], a["pc"]
         rx, ox = x.resolve()
         ry, oy = y.resolve()
@@ -580,6 +618,11 @@ def _op_info(kind, a):
                     flops=flops,
                     bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
+    if kind == "bottleneck":
+        x, y = a["x"], a["y"]
+        px = y.N * y.H * y.W
+        return dict(kind="conv", label="bottleneck_c32", flops=2.0 * px * 32 * 32 * 10,
+                    bytes=px * 32 * 2 * 2 + (32 * 32 + 32 * 288) * 2, shape=(x.N, x.H, x.W, 32, 32, 3, 1))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
         return dict(kind="conv", label="conv_focus3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,

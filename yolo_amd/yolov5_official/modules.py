@@ -77,6 +77,9 @@ class Bottleneck(nn.Module):
         return x + y if self.add else y
 
     def lower(self, g, x, out=None):
+        a1, a2 = activation_code(self.cv1.act), activation_code(self.cv2.act)
+        if a1 == a2 and a1[0] != _ffi.ACT_NONE:
+            return g.bottleneck(x, (self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn), *a1, add=self.add, out=out)
         return self.cv2.lower(g, self.cv1.lower(g, x), out=out, res=x if self.add else None)
 
 
@@ -135,6 +138,20 @@ class C3(nn.Module):
             # cv1 and cv2 read the same input: one convolution writes [cv1(x) | cv2(x)] straight into the concat buffer;
             # the bottleneck chain then updates the first half in place (its residual is read by the thread that
             # overwrites it), so the concat never exists as an operation.
+            if c_ == 32 and g.dt == _ffi.BF16:
+                # 32-channel bottlenecks run as one kernel that must not work in place (it reads a halo): the sibling
+                # conv writes [cv2(x) | cv1(x)] behind a free slot, the chain alternates between the two outer slots
+                # and ends in the first one, so that cv3 reads channels [0, 64) = [m(cv1(x)) | cv2(x)]
+                n = len(self.m)
+                order = [(self.cv2.conv, self.cv2.bn), (self.cv1.conv, self.cv1.bn)]
+                if n % 2 == 0:
+                    order = [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)]
+                wide, parts = g.conv_siblings(x, order, *a1, lead=c_ if n % 2 else 0, tail=0 if n % 2 else c_)
+                front, back = g.slice(wide, 0, c_), g.slice(wide, 2 * c_, c_)
+                y = back if n % 2 else front
+                for b in self.m:
+                    y = b.lower(g, y, out=front if y is back else back)
+                return self.cv3.lower(g, g.slice(wide, 0, 2 * c_))
             cat, (y, _) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1)
             for b in self.m:
                 b.lower(g, y, out=y)
