@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 5
+#define YDET_ABI_VERSION 6
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -92,6 +92,13 @@ typedef struct {
     const float* post_shift;
     int32_t post_act;  /* ydet_act */
     float post_slope;
+    /* Optional second destination: output channels [y_split, Cout) are written to the slice (y2, y2_ld, y2_coff)
+     * instead of y, which then holds channels [0, y_split) only.  Lets one convolution stand for two that read the
+     * same input but feed different buffers (C3: cv1 -> the bottleneck chain, cv2 -> the concat,
+     * yolov5_official/modules.py:252).  y_split and Cout multiples of 8 (bf16) / 4 (f32); needs Cin a multiple of
+     * the K step and Cout > 32; excludes res and cout_store.  NULL = one destination. */
+    void* y2;
+    int32_t y2_ld, y2_coff, y_split;
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 

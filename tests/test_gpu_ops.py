@@ -459,3 +459,30 @@ def test_bottleneck_c32_rejects_in_place():
         d.x_ld = d.y_ld = 32
         d.kp, d.cout_pad, d.act, d.in_dtype, d.out_dtype = kp, 128, _ffi.ACT_SILU, _ffi.BF16, _ffi.BF16
     assert lib.ydet_bottleneck_c32(c1, c2, None) == -1 and b"overlaps" in lib.ydet_last_error()
+
+
+@pytest.mark.parametrize("c0,c1,cin,k", [(32, 32, 64, 1), (64, 24, 32, 3), (8, 128, 96, 1)])
+def test_conv_second_destination(c0, c1, cin, k):
+    """One convolution standing for two that read the same input: channels [0, c0) go to one buffer, the rest to a
+    channel slice of another (here: the second half of a concat); bit-identical to the single-destination conv."""
+    g = _gen(11, f"split{c0}{c1}")
+    convs = [nn.Conv2d(cin, c, k, 1, k // 2, bias=True) for c in (c0, c1)]
+    for c in convs:
+        with torch.no_grad():
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+            c.bias.copy_(torch.randn(c.bias.shape, generator=g) * 0.1)
+    x = torch.randn(2, cin, 19, 23, generator=g)
+
+    def joint(gr, ins):
+        out, _ = gr.conv_siblings(ins[0], [(c, None) for c in convs], _ffi.ACT_SILU)
+        gr.to_nchw(out, "y")
+
+    def separate(gr, ins):
+        _, (a, b) = gr.conv_siblings(ins[0], [(c, None) for c in convs], _ffi.ACT_SILU, separate=True)
+        cat = gr.cat([gr.maxpool2s1(a), b])          # b is redirected into the concat buffer, a stays on its own
+        gr.to_nchw(a, "a")
+        gr.to_nchw(gr.slice(cat, c0, c1), "b")
+
+    ref = _run_graph(joint, x, compute="bf16")["y"].float().cpu()
+    out = _run_graph(separate, x, compute="bf16")
+    assert torch.equal(out["a"].float().cpu(), ref[:, :c0]) and torch.equal(out["b"].float().cpu(), ref[:, c0:])

@@ -142,8 +142,10 @@ def test_planner_v5s_on_cpu():
     assert kinds[0] == "focus_conv" and kinds.count("conv") == 48 and kinds.count("bottleneck") == 1
     assert kinds.count("head_decode") == 3 and "copy" not in kinds
     assert kinds.count("spp") == 1 and kinds.count("upsample") == 2
-    bn = [op for op in plan.ops if op.kind == 11][0]          # reads the back slot, writes the front slot of a 96-wide buffer
-    assert (bn.conv.x_ld, bn.conv.x_coff, bn.conv2.y_ld, bn.conv2.y_coff, bn.conv2.res_coff) == (96, 64, 96, 0, 64)
+    bn = [op for op in plan.ops if op.kind == 11][0]          # reads cv1's own buffer, writes the first half of the concat
+    assert (bn.conv.x_ld, bn.conv.x_coff, bn.conv2.y_ld, bn.conv2.y_coff, bn.conv2.res_ld) == (32, 0, 64, 0, 32)
+    sib = plan.ops[1 + 1]                                     # the C3's sibling conv: cv1 -> that buffer, cv2 -> concat half 2
+    assert (sib.conv.Cout, sib.conv.y_split, sib.conv.y_ld, sib.conv.y2_ld, sib.conv.y2_coff) == (64, 32, 32, 64, 32)
     gflop = sum(i["flops"] for i in plan.op_info) / 2 / 1e9
     assert abs(gflop - 16.96) < 0.01          # conv FLOPs per 640x640 image of YOLOv5s
     g32 = engine.Graph("cpu", "fp32")      # the fp32 path keeps the layout kernel + a regular first convolution

@@ -58,6 +58,9 @@ struct ConvArgs {
     const float* post_shift;
     int post_act;
     float post_slope;
+    char* y2;         // second destination: output channels y_split.. go to y2 (slice y2_ld / y2_coff), or null
+    int y2_ld, y2_coff;
+    int y_split;      // INT_MAX without a second destination
 };
 
 // Detect decode of one pyramid level, done in the epilogue of its 1x1 prediction convolution (the tile holds all
@@ -765,7 +768,10 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                     const int co = n0 + piece * V;
                     if (m < a.M && co < a.cout_store) {
                         const u32x4 v = *reinterpret_cast<const u32x4*>(smem + pl * ROWB + piece * 16);
-                        *reinterpret_cast<u32x4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT)) = v;
+                        // channels from y_split on belong to the second destination
+                        char* dst = co >= a.y_split ? a.y2 + ((size_t)m * a.y2_ld + a.y2_coff + (co - a.y_split)) * sizeof(TOUT)
+                                                    : a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT);
+                        *reinterpret_cast<u32x4*>(dst) = v;
                     }
                 }
             }
@@ -821,11 +827,13 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float)));
             if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         }
+        if (a.y2 && !a.lds_epilogue) return fail(YDET_ERR_ARG, "conv: a second destination needs 16-byte aligned output slices");
         hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
                            dim3(64 * NW), lds_dma, stream, a, HeadArgs{});
         YDET_CHECK_LAUNCH("conv_dma_kernel");
         return YDET_OK;
     }
+    if (a.y2) return fail(YDET_ERR_ARG, "conv: a second destination needs Cin to be a multiple of %d and at least 64 output channels", BK);
     if constexpr (WARPS_N * WARPS_M != 4) {
         return fail(YDET_ERR_ARG, "conv: the %dx%d tile needs Cin to be a multiple of %d", BN, BM, BK);
     } else {
@@ -898,7 +906,16 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     YDET_CHECK_ARG(d->Cin % epc == 0 && d->x_ld % epc == 0 && d->x_coff % epc == 0,
                    "conv: Cin/x_ld/x_coff (%d,%d,%d) must be multiples of %d", d->Cin, d->x_ld, d->x_coff, epc);
     YDET_CHECK_ARG(d->x_coff >= 0 && d->x_coff + d->Cin <= d->x_ld, "conv: input slice exceeds x_ld");
-    YDET_CHECK_ARG(d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld, "conv: output slice exceeds y_ld");
+    const int y_ch = d->y2 ? d->y_split : d->Cout;   // channels that land in y
+    YDET_CHECK_ARG(d->y_coff >= 0 && d->y_coff + y_ch <= d->y_ld, "conv: output slice exceeds y_ld");
+    if (d->y2) {
+        const int vec = d->out_dtype == YDET_BF16 ? 8 : 4;
+        YDET_CHECK_ARG(d->y_split > 0 && d->y_split < d->Cout && d->y_split % vec == 0 && d->Cout % vec == 0 &&
+                           d->y2_ld % vec == 0 && d->y2_coff % vec == 0 && d->y2_coff >= 0 &&
+                           d->y2_coff + d->Cout - d->y_split <= d->y2_ld && ((uintptr_t)d->y2 & 15) == 0,
+                       "conv: second destination (split %d of %d channels, ld %d, coff %d)", d->y_split, d->Cout, d->y2_ld, d->y2_coff);
+        YDET_CHECK_ARG(d->cout_store == 0 && d->res == nullptr, "conv: a second destination excludes cout_store and a residual");
+    }
     YDET_CHECK_ARG(d->cout_store == 0 || (d->cout_store >= d->Cout && d->cout_store <= d->cout_pad &&
                                           d->y_coff + d->cout_store <= d->y_ld),
                    "conv: cout_store %d (need Cout <= cout_store <= cout_pad and inside y_ld)", d->cout_store);
@@ -930,6 +947,8 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     a.lds_epilogue = 0;
     a.post_scale = d->post_scale; a.post_shift = d->post_shift; a.post_act = d->post_act; a.post_slope = d->post_slope;
     a.cout_store = d->cout_store > 0 ? d->cout_store : d->Cout;
+    a.y2 = (char*)d->y2; a.y2_ld = d->y2_ld; a.y2_coff = d->y2_coff;
+    a.y_split = d->y2 ? d->y_split : 0x7fffffff;
     a.vec_store = (d->Cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0 &&
                    (!d->res || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0)))
                       ? 1

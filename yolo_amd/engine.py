@@ -173,11 +173,12 @@ class Graph:
         assert 0 <= off and off + C <= t.C
         return T(t.st, t.coff + off, C)
 
-    def conv_siblings(self, x, pairs, act=_ffi.ACT_NONE, slope=0.0, lead=0, tail=0):
+    def conv_siblings(self, x, pairs, act=_ffi.ACT_NONE, slope=0.0, separate=False):
         """Several (conv, bn) pairs that read the same input with the same geometry and activation, run as ONE
         convolution whose output channels are the pairs' outputs side by side (the input is read once).
-        Returns (buffer, list of the pairs' channel slices in order); they share one storage, which has `lead`
-        free channels in front of the outputs and `tail` behind them."""
+        Returns (buffer, list of the pairs' channel slices in order); they share one storage.  With `separate` (two
+        pairs, LDS-DMA kernel shapes only) each pair gets a storage of its own (the convolution's second destination)
+        and the buffer returned is None."""
         folded = [fold_conv(c, b, None, self.device) for c, b in pairs]
         first = pairs[0][0]
         for c, _ in pairs[1:]:
@@ -188,10 +189,19 @@ class Graph:
         s, p = first.stride[0], first.padding[0]
         Ho = (x.H + 2 * p - pc.KH) // s + 1
         Wo = (x.W + 2 * p - pc.KW) // s + 1
-        out = self.new(x.N, Ho, Wo, lead + pc.Cout + tail)
-        self.ops.append(("conv", dict(x=x, y=T(out.st, lead, pc.Cout), res=None, pc=pc, stride=s, pad=p, act=act,
-                                      slope=float(slope), res_mode=_ffi.RES_NONE, post=None)))
-        parts, off = [], lead
+        if separate:
+            c0, c1 = folded[0][0].shape[0], folded[1][0].shape[0]
+            bk = 32 if self.dt == _ffi.BF16 else 16
+            assert len(pairs) == 2 and c0 % self.vec == 0 and c1 % self.vec == 0 and c0 + c1 > 32 and x.C % bk == 0, \
+                "separate sibling outputs need the LDS-DMA convolution"
+            y, y2 = self.new(x.N, Ho, Wo, c0), self.new(x.N, Ho, Wo, c1)
+            self.ops.append(("conv", dict(x=x, y=y, y2=y2, res=None, pc=pc, stride=s, pad=p, act=act,
+                                          slope=float(slope), res_mode=_ffi.RES_NONE, post=None)))
+            return None, [y, y2]
+        out = self.new(x.N, Ho, Wo, pc.Cout)
+        self.ops.append(("conv", dict(x=x, y=out, res=None, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
+                                      res_mode=_ffi.RES_NONE, post=None)))
+        parts, off = [], 0
         for w, _ in folded:
             parts.append(T(out.st, off, w.shape[0]))
             off += w.shape[0]
@@ -459,6 +469,10 @@ class Plan:
         d.kp, d.cout_pad = pc.kp, pc.cout_pad
         d.act, d.slope, d.res_mode = a["act"], a["slope"], a["res_mode"]
         d.in_dtype, d.out_dtype = rx.dtype, ry.dtype
+        if a.get("y2") is not None:
+            r2, o2 = a["y2"].resolve()
+            assert r2.dtype == ry.dtype and not r2.external
+            d.y2, d.y2_ld, d.y2_coff, d.y_split = arena[r2].data_ptr(), r2.ld, o2, y.C
         if a.get("post") is not None:
             ps, pb, pact, pslope = a["post"]
             d.post_scale, d.post_shift, d.post_act, d.post_slope = ps.data_ptr(), pb.data_ptr(), pact, pslope
@@ -611,7 +625,7 @@ def _op_info(kind, a):
     if kind == "conv":
         x, y, pc = a["x"], a["y"], a["pc"]
         flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.cin_real * pc.KH * pc.KW
-        nbytes = x.N * x.H * x.W * x.C * esz(x) + y.N * y.H * y.W * y.C * esz(y) + pc.Cout * pc.KH * pc.KW * x.C * esz(x)
+        nbytes = x.N * x.H * x.W * x.C * esz(x) + y.N * y.H * y.W * pc.Cout * esz(y) + pc.Cout * pc.KH * pc.KW * x.C * esz(x)
         if a["res"] is not None:
             nbytes += y.N * y.H * y.W * y.C * esz(x)
         return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W),

@@ -138,20 +138,14 @@ class C3(nn.Module):
             # cv1 and cv2 read the same input: one convolution writes [cv1(x) | cv2(x)] straight into the concat buffer;
             # the bottleneck chain then updates the first half in place (its residual is read by the thread that
             # overwrites it), so the concat never exists as an operation.
-            if c_ == 32 and g.dt == _ffi.BF16:
+            if c_ == 32 and g.dt == _ffi.BF16 and x.C % 32 == 0:
                 # 32-channel bottlenecks run as one kernel that must not work in place (it reads a halo): the sibling
-                # conv writes [cv2(x) | cv1(x)] behind a free slot, the chain alternates between the two outer slots
-                # and ends in the first one, so that cv3 reads channels [0, 64) = [m(cv1(x)) | cv2(x)]
-                n = len(self.m)
-                order = [(self.cv2.conv, self.cv2.bn), (self.cv1.conv, self.cv1.bn)]
-                if n % 2 == 0:
-                    order = [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)]
-                wide, parts = g.conv_siblings(x, order, *a1, lead=c_ if n % 2 else 0, tail=0 if n % 2 else c_)
-                front, back = g.slice(wide, 0, c_), g.slice(wide, 2 * c_, c_)
-                y = back if n % 2 else front
+                # conv sends cv1(x) to a buffer of its own and cv2(x) to what becomes the second half of the concat
+                # buffer; the last bottleneck's output becomes the first half
+                _, (y, y2) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1, separate=True)
                 for b in self.m:
-                    y = b.lower(g, y, out=front if y is back else back)
-                return self.cv3.lower(g, g.slice(wide, 0, 2 * c_))
+                    y = b.lower(g, y)
+                return self.cv3.lower(g, g.cat([y, y2]))
             cat, (y, _) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1)
             for b in self.m:
                 b.lower(g, y, out=y)
