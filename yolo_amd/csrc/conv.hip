@@ -438,23 +438,41 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     const char* xsrc[XJ];
     unsigned xmask[XJ];
     const int HoWo = a.Ho * a.Wo;
+    // (image, row, column) of the tile's first pixel: one wave-uniform pair of divisions (M < 2^31, checked on the
+    // host); a lane's pixels are at most BM further on, which float reciprocals resolve exactly
+    int n_0 = 0, ho_0 = 0, wo_0 = 0;
+    float r_wo = 0.f, r_ho = 0.f;
+    if (!pointwise) {
+        const unsigned mu = (unsigned)m0;
+        n_0 = (int)(mu / (unsigned)HoWo);
+        const unsigned rem = mu - (unsigned)n_0 * (unsigned)HoWo;
+        ho_0 = (int)(rem / (unsigned)a.Wo);
+        wo_0 = (int)(rem - (unsigned)ho_0 * (unsigned)a.Wo);
+        r_wo = 1.0f / (float)a.Wo;
+        r_ho = 1.0f / (float)a.Ho;
+    }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-        const long long m = m0 + (j * NW + wave) * 16 + srow;
+        const int row = (j * NW + wave) * 16 + srow;
+        const long long m = m0 + row;
         const bool okm = m < a.M;
-        const long long mm = okm ? m : 0;
         if (pointwise) {
-            xsrc[j] = a.x + ((size_t)mm * a.x_ld + a.x_coff + lchunk * EPC) * sizeof(TIN);
+            xsrc[j] = a.x + ((size_t)(okm ? m : 0) * a.x_ld + a.x_coff + lchunk * EPC) * sizeof(TIN);
             xmask[j] = okm ? 1u : 0u;
         } else {
-            // M < 2^31 (checked on the host): 32-bit divisions, and no division at all in the tap walk
-            const unsigned mu = (unsigned)mm;
-            const int n = (int)(mu / (unsigned)HoWo);
-            const int rem = (int)(mu - (unsigned)n * (unsigned)HoWo);
-            const int ho = (int)((unsigned)rem / (unsigned)a.Wo), wo = rem - ho * a.Wo;
+            // no division in the tap walk either: validity of each tap is one bit of a mask
+            const int cw = wo_0 + row, qw = div_small(cw, a.Wo, r_wo), wo = cw - qw * a.Wo;
+            const int ch = ho_0 + qw, qh = div_small(ch, a.Ho, r_ho), ho = ch - qh * a.Ho;
+            const int n = n_0 + qh;
             const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
             unsigned mk = 0;
-            if (okm) {
+            if (a.KH == 3 && a.KW == 3) {      // the common case, unrolled
+                unsigned colm = 0;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) colm |= (unsigned)(wi0 + kw) < (unsigned)a.W ? 1u << kw : 0u;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) mk |= (unsigned)(hi0 + kh) < (unsigned)a.H ? colm << (3 * kh) : 0u;
+            } else {
                 unsigned bit = 1u;
                 for (int kh = 0; kh < a.KH; ++kh) {
                     const bool rowok = (unsigned)(hi0 + kh) < (unsigned)a.H;
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                         if (rowok && (unsigned)(wi0 + kw) < (unsigned)a.W) mk |= bit;
                 }
             }
-            xmask[j] = mk;
+            xmask[j] = okm ? mk : 0u;
             const long long pix = ((long long)n * a.H + hi0) * a.W + wi0;  // may be "before" the image: masked
             xsrc[j] = a.x + (pix * a.x_ld + a.x_coff + lchunk * EPC) * (long long)sizeof(TIN);
         }
@@ -933,6 +951,7 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     if (d->res) YDET_CHECK_ARG(d->res_coff >= 0 && d->res_coff + d->Cout <= d->res_ld, "conv: residual slice");
     YDET_CHECK_ARG((long long)d->H * d->W * d->x_ld < (1LL << 31), "conv: one image exceeds 2^31 elements");
     YDET_CHECK_ARG((long long)d->N * d->Ho * d->Wo < (1LL << 31), "conv: more than 2^31 output pixels");
+    YDET_CHECK_ARG(d->Ho < (1 << 21) && d->Wo < (1 << 21), "conv: output map side beyond 2^21");
 
     a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.res = (const char*)d->res;
     a.y = (char*)d->y;
