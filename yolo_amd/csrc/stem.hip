@@ -69,36 +69,50 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
         for (int s = 0; s < KSTEPS; ++s)
             wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)(32 * (i >> 1) + 4 * (i & 1) + wrow) * (KSTEPS * 32) + s * 32 + (lane >> 4) * 8) * 2);
 
-    // ---- image patch -> LDS focus tile ----------------------------------------------------------------
-    constexpr int NPAIR = 3 * (2 * FH) * FW;            // 2040 pairs: (channel, image row, focus column)
-    constexpr int PER_THREAD = (NPAIR + 255) / 256;
-    pair_t px[PER_THREAD];
-    bool ok[PER_THREAD];
+    // ---- image patch -> LDS focus tile: a thread builds whole focus pixels (2 x 2 image pixels x 3 channels = six
+    // 2-pixel loads) and writes each as two 16-byte pieces, zero channels included ------------------------------------
+    constexpr int NFP = FH * FW;                        // 340 focus pixels
+    constexpr int ITER = (NFP + 255) / 256;
+    pair_t px[ITER][6];
     const TX* img = reinterpret_cast<const TX*>(a.x) + (size_t)n * 3 * a.H * a.W;
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) {
-        const int idx = tid + 256 * k;
-        const int c = idx / (2 * FH * FW), rem = idx - c * (2 * FH * FW);
-        const int ry = rem / FW, fx = rem - ry * FW;
-        const int Y = y0 + ry, X = x0 + 2 * fx;
-        ok[k] = idx < NPAIR && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
-        px[k] = pair_t();
-        if (ok[k]) px[k] = *reinterpret_cast<const pair_t*>(img + ((size_t)c * a.H + Y) * a.W + X);
-    }
-    for (int p = tid; p < FH * FW; p += 256)            // channels 12..15 of every focus pixel
-        *reinterpret_cast<unsigned long long*>(F + p * 16 + 12) = 0ull;
+    for (int it = 0; it < ITER; ++it) {
+        const int fp = tid + 256 * it;
+        const int fy = fp / FW, fx = fp - fy * FW;
+        const int Y = y0 + 2 * fy, X = x0 + 2 * fx;     // X and W are even: a pair is inside or outside as a whole
+        const bool colok = fp < NFP && (unsigned)X < (unsigned)a.W;
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) {
-        const int idx = tid + 256 * k;
-        if (idx >= NPAIR) continue;
-        const int c = idx / (2 * FH * FW), rem = idx - c * (2 * FH * FW);
-        const int ry = rem / FW, fx = rem - ry * FW;
-        float v0, v1;
-        Pair<TX>::split(px[k], v0, v1);
-        __bf16* f = F + ((ry >> 1) * FW + fx) * 16;
-        const int dy = ry & 1;
-        f[dy * 3 + c] = (__bf16)v0;          // (dy, dx = 0)
-        f[(2 + dy) * 3 + c] = (__bf16)v1;    // (dy, dx = 1)
+        for (int dy = 0; dy < 2; ++dy) {
+            const bool ok = colok && (unsigned)(Y + dy) < (unsigned)a.H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                px[it][dy * 3 + c] = pair_t();
+                if (ok) px[it][dy * 3 + c] = *reinterpret_cast<const pair_t*>(img + ((size_t)c * a.H + Y + dy) * a.W + X);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int fp = tid + 256 * it;
+        if (fp >= NFP) continue;
+        bf16x8 lo, hi;                                   // focus channels 0..7 and 8..15 (12..15 zero)
+        __bf16 ch[16];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v0, v1;
+                Pair<TX>::split(px[it][dy * 3 + c], v0, v1);
+                ch[dy * 3 + c] = (__bf16)v0;            // (dy, dx = 0)
+                ch[(2 + dy) * 3 + c] = (__bf16)v1;      // (dy, dx = 1)
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            lo[e] = ch[e];
+            hi[e] = e < 4 ? ch[8 + e] : (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(F + fp * 16) = lo;
+        *reinterpret_cast<bf16x8*>(F + fp * 16 + 8) = hi;
     }
     __syncthreads();
 
