@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--split", type=int, default=1, choices=[1, 2, 4],
                     help="run the forward pass as this many side-by-side launch lists over slices of the batch; with a "
                          "split the per-kernel events are taken in a second, unsplit loop outside the timed region")
+    ap.add_argument("--event-every", type=int, default=5,
+                    help="per-op events (kernel durations for the roofline object) are recorded on every E-th timed "
+                         "step: an event costs about 3 us of stream time, 57 of them per step are 5 %% of it")
     args = ap.parse_args()
 
     import yolo_amd
@@ -100,21 +103,27 @@ def main():
             step()
         torch.cuda.synchronize()
         n_ops = len(plan_holder["plan"].ops)
-        timer = lib.ydet_timer_create(args.steps * (n_ops + 1))
+        sampled = [k for k in range(args.steps) if k % max(args.event_every, 1) == 0]   # steps that carry events
+        n_ev = len(sampled)
+        timer = lib.ydet_timer_create(n_ev * (n_ops + 1))
         if not timer:
             raise RuntimeError("ydet_timer_create failed")
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
 
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         split = plan_holder["plan"].R > 1
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # step boundaries
         for k in range(args.steps):
-            if split:
+            marks[k].record()
+            if split or k not in sampled:
                 step()
             else:
-                step(timer, k * (n_ops + 1), evs[k])
+                j = sampled.index(k)
+                step(timer, j * (n_ops + 1), evs[j])
+        marks[args.steps].record()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -124,8 +133,8 @@ def main():
             model.invalidate_plans()
             step()
             torch.cuda.synchronize()
-            for k in range(args.steps):
-                step(timer, k * (n_ops + 1), evs[k])
+            for j in range(n_ev):
+                step(timer, j * (n_ops + 1), evs[j])
             torch.cuda.synchronize()
 
     if world > 1:
@@ -145,20 +154,30 @@ def main():
     _ffi.check(lib.ydet_timer_elapsed(cal, 0, ncal - 1, gaps), "ydet_timer_elapsed")
     lib.ydet_timer_destroy(cal)
     event_ms = sorted(gaps)[(ncal - 1) // 2]
+    event_src = "median gap of 50 back-to-back events"
+    # Better when the timed region has steps with and without events: what an event really adds to the stream is the
+    # difference of their mean durations, spread over the events of a step (back-to-back events overstate it, a
+    # kernel in between hides part of the event's processing).
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    plain = [step_ms[k] for k in range(args.steps) if k not in sampled]
+    if not split and plain and sampled:
+        with_ev = [step_ms[k] for k in sampled]
+        event_ms = max((sum(with_ev) / len(with_ev) - sum(plain) / len(plain)) / (n_ops + 4), 0.0)
+        event_src = "mean duration of timed steps with events minus without, per event"
     plan = plan_holder["plan"]
     per_label = {}
     buf = (ctypes.c_float * n_ops)()
-    for k in range(args.steps):
+    for k in range(n_ev):
         _ffi.check(lib.ydet_timer_elapsed(timer, k * (n_ops + 1), n_ops, buf), "ydet_timer_elapsed")
         for i, info in enumerate(plan.op_info):
             d = per_label.setdefault(info["label"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d["ms"] += max(buf[i] - event_ms, 1e-4); d["launches"] += 1; d["flops"] += info["flops"]; d["bytes"] += info["bytes"]
     if args.per_op and rank == 0:
         per_op = [0.0] * n_ops
-        for k in range(args.steps):
+        for k in range(n_ev):
             _ffi.check(lib.ydet_timer_elapsed(timer, k * (n_ops + 1), n_ops, buf), "ydet_timer_elapsed")
             for i in range(n_ops):
-                per_op[i] += buf[i] / args.steps
+                per_op[i] += max(buf[i] - event_ms, 1e-4) / n_ev
         with open(args.per_op, "w") as fh:
             fh.write("op\tlabel\tshape(N,H,W,Cin,Cout,k,s)\tus\tTFLOP/s\tGB/s\n")
             for i, info in enumerate(plan.op_info):
@@ -166,8 +185,8 @@ def main():
                 fh.write(f"{i}\t{info['label']}\t{info.get('shape', '')}\t{us:.1f}\t{info['flops'] / (us * 1e-6) / 1e12:.1f}\t"
                          f"{info['bytes'] / (us * 1e-6) / 1e9:.0f}\n")
     lib.ydet_timer_destroy(timer)
-    decode_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
-    nms_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+    decode_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / n_ev
+    nms_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / n_ev
     conv = {k: v for k, v in per_label.items() if k.startswith("conv")}
     conv_ms = sum(v["ms"] for v in conv.values())
     conv_flops = sum(v["flops"] for v in conv.values())
@@ -175,7 +194,7 @@ def main():
     peak = PEAK_TFLOPS[args.compute]
     dom_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     stack_tf = conv_flops / (conv_ms * 1e-3) / 1e12
-    kernels = {k: dict(avg_us=round(v["ms"] / v["launches"] * 1e3, 2), launches_per_step=v["launches"] // args.steps,
+    kernels = {k: dict(avg_us=round(v["ms"] / v["launches"] * 1e3, 2), launches_per_step=v["launches"] // n_ev,
                        tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                        gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
                for k, v in sorted(per_label.items(), key=lambda kv: -kv[1]["ms"])}
@@ -215,13 +234,14 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dom_label, "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(dom_tf / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
-                     "launches_per_step": dom["launches"] // args.steps,
+                     "launches_per_step": dom["launches"] // n_ev,
+                     "launches_measured": dom["launches"], "event_steps": n_ev,
                      "flops_per_launch": dom["flops"] / dom["launches"],
                      "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
-                     "event_overhead_us": round(event_ms * 1e3, 2)},
+                     "event_overhead_us": round(event_ms * 1e3, 2), "event_overhead_source": event_src},
         "conv_stack": {"tflops": round(stack_tf, 2), "mfma_util_frac": round(stack_tf / peak, 4),
-                       "ms_per_step": round(conv_ms / args.steps, 3),
-                       "gflop_per_image": round(conv_flops / args.steps / args.batch / 1e9, 3)},
+                       "ms_per_step": round(conv_ms / n_ev, 3),
+                       "gflop_per_image": round(conv_flops / n_ev / args.batch / 1e9, 3)},
         "decode": {"ms_per_step": round(decode_ms, 3), "gbs": round(decode_bytes / (decode_ms * 1e-3) / 1e9, 1),
                    "frac_of_hbm_peak": round(decode_bytes / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "nms": {"ms_per_step": round(nms_ms, 3), "gbs": round(nms_bytes / (nms_ms * 1e-3) / 1e9, 1),

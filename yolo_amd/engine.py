@@ -635,7 +635,7 @@ def _op_info(kind, a):
     if kind == "bottleneck":
         x, y = a["x"], a["y"]
         px = y.N * y.H * y.W
-        return dict(kind="conv", label="bottleneck_c32", flops=2.0 * px * 32 * 32 * 10,
+        return dict(kind="conv", label="conv_bottleneck_c32", flops=2.0 * px * 32 * 32 * 10,
                     bytes=px * 32 * 2 * 2 + (32 * 32 + 32 * 288) * 2, shape=(x.N, x.H, x.W, 32, 32, 3, 1))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
