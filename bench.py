@@ -83,8 +83,6 @@ def main():
         plan_holder["plan"] = plan
         outs = plan.run(x, timer=timer, first_mark=mark)
         det_head = model.model[-1]
-        if ev is not None:
-            ev[0].record()
         z, _ = det_head.finish(outs)
         if ev is not None:
             ev[1].record()
@@ -185,7 +183,6 @@ def main():
                 fh.write(f"{i}\t{info['label']}\t{info.get('shape', '')}\t{us:.1f}\t{info['flops'] / (us * 1e-6) / 1e12:.1f}\t"
                          f"{info['bytes'] / (us * 1e-6) / 1e9:.0f}\n")
     lib.ydet_timer_destroy(timer)
-    decode_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / n_ev
     nms_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / n_ev
     conv = {k: v for k, v in per_label.items() if k.startswith("conv")}
     conv_ms = sum(v["ms"] for v in conv.values())
@@ -200,7 +197,6 @@ def main():
                for k, v in sorted(per_label.items(), key=lambda kv: -kv[1]["ms"])}
 
     n_boxes = 3 * (args.size // 8) ** 2 + 3 * (args.size // 16) ** 2 + 3 * (args.size // 32) ** 2
-    decode_bytes = 2.0 * args.batch * n_boxes * 85 * 4
     nms_bytes = args.batch * n_boxes * 85 * 4 + args.batch * 300 * 6 * 4
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes
@@ -242,8 +238,7 @@ def main():
         "conv_stack": {"tflops": round(stack_tf, 2), "mfma_util_frac": round(stack_tf / peak, 4),
                        "ms_per_step": round(conv_ms / n_ev, 3),
                        "gflop_per_image": round(conv_flops / n_ev / args.batch / 1e9, 3)},
-        "decode": {"ms_per_step": round(decode_ms, 3), "gbs": round(decode_bytes / (decode_ms * 1e-3) / 1e9, 1),
-                   "frac_of_hbm_peak": round(decode_bytes / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "decode": "in the epilogue of the three prediction convolutions (kernel conv_head_decode)",
         "nms": {"ms_per_step": round(nms_ms, 3), "gbs": round(nms_bytes / (nms_ms * 1e-3) / 1e9, 1),
                 "frac_of_hbm_peak": round(nms_bytes / (nms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels": kernels,
