@@ -57,12 +57,13 @@ struct NmsShared {
 };
 
 // Greedy NMS over `ns` boxes already sorted by descending priority.  load(s) returns box s.
-// removed / kept: LDS bitsets of (ns+63)/64 words, zeroed here.  256 threads.
-template <bool EPS_LE, typename LoadBox>
+// removed / kept: LDS bitsets of (ns+63)/64 words, zeroed here.  NT threads (256 or 1024).
+template <bool EPS_LE, int NT = 256, typename LoadBox>
 __device__ void greedy_nms_block(int ns, float thr, LoadBox load, NmsShared& sh, u64* removed, u64* kept) {
+    constexpr int PARTS = NT / 64, PER = 64 / PARTS;   // threads per box of a chunk, boxes each of them tests
     const int tid = threadIdx.x;
     const int nwords = (ns + 63) >> 6;
-    for (int w = tid; w < nwords; w += 256) { removed[w] = 0; kept[w] = 0; }
+    for (int w = tid; w < nwords; w += NT) { removed[w] = 0; kept[w] = 0; }
     __syncthreads();
     for (int c = 0; c < nwords; ++c) {
         const int base = c << 6;
@@ -74,45 +75,56 @@ __device__ void greedy_nms_block(int ns, float thr, LoadBox load, NmsShared& sh,
             sh.carea[tid] = box_area(b);
         }
         __syncthreads();
-        // phase A: thread (i = tid>>2, part = tid&3) tests j = part*16 .. part*16+15, j > i
+        // phase A: thread (i = tid / PARTS, part = tid % PARTS) tests j = part*PER .. part*PER+PER-1, j > i
         {
-            const int i = tid >> 2, part = tid & 3;
+            const int i = tid / PARTS, part = tid % PARTS;
             u64 bits = 0;
             if (i < cn) {
                 const float4 bi = sh.cbox[i];
                 const float ai = sh.carea[i];
-                for (int jj = 0; jj < 16; ++jj) {
-                    const int j = part * 16 + jj;
+#pragma unroll
+                for (int jj = 0; jj < PER; ++jj) {
+                    const int j = part * PER + jj;
                     if (j > i && j < cn && suppresses<EPS_LE>(bi, ai, sh.cbox[j], sh.carea[j], thr))
                         bits |= 1ull << j;
                 }
             }
-            bits |= __shfl_xor(bits, 1);
-            bits |= __shfl_xor(bits, 2);
+#pragma unroll
+            for (int d = 1; d < PARTS; d <<= 1) bits |= __shfl_xor(bits, d);
             if (part == 0) sh.rowmask[i] = bits;
         }
         __syncthreads();
-        // phase B: serial walk over the chunk
-        if (tid == 0) {
+        // phase B: serial walk over the chunk.  One wave, lane i holds row i's mask; the walk visits only boxes still
+        // alive and fetches their masks with readlane (wave-uniform, no LDS round trip per step)
+        if (tid < 64) {
+            const u64 mine = tid < cn ? sh.rowmask[tid] : 0ull;
+            const u64 valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
             u64 rem = removed[c], kp = 0;
-            for (int i = 0; i < cn; ++i) {
-                if (!((rem >> i) & 1ull)) {
-                    kp |= 1ull << i;
-                    rem |= sh.rowmask[i];
-                }
+            u64 cand = ~rem & valid;
+            while (cand) {
+                const int i = __ffsll((long long)cand) - 1;
+                kp |= 1ull << i;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, i);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), i);
+                rem |= ((u64)hi << 32) | (u64)lo;
+                cand = ~rem & valid & ~(((1ull << i) << 1) - 1ull);   // alive and behind i
             }
-            kept[c] = kp;
-            sh.kept_word = kp;
+            if (tid == 0) {
+                kept[c] = kp;
+                sh.kept_word = kp;
+            }
         }
         __syncthreads();
         // phase C: kept boxes of this chunk against every later box
         const u64 kp = sh.kept_word;
         if (kp) {
-            for (int j = base + 64 + tid; j < ns; j += 256) {
+            constexpr int CP = NT >= 1024 ? 4 : 1;     // threads per later box, each takes 64 / CP of the chunk's boxes
+            for (int t = tid; t < (ns - base - 64) * CP; t += NT) {
+                const int j = base + 64 + t / CP;
                 if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
                 const float4 bj = load(j);
                 const float aj = box_area(bj);
-                u64 m = kp;
+                u64 m = CP == 1 ? kp : kp & (((1ull << (64 / CP)) - 1ull) << ((t % CP) * (64 / CP)));
                 while (m) {
                     const int i = __ffsll((long long)m) - 1;
                     m &= m - 1;
@@ -137,6 +149,7 @@ constexpr int kTileFloats = 8192;  // LDS staging tile of prediction rows (exact
 constexpr int kScanRows = 128;     // rows per workgroup of the row-maximum scan
 constexpr int kScanTile = 11008;   // floats of its LDS tile (128 rows of 85 + slack)
 constexpr int kPickThreads = 1024;
+constexpr int kNmsLdsBoxes = 1024; // sorted boxes the greedy NMS keeps in LDS (16 KB)
 
 struct V5Meta {  // per image, 16 words
     unsigned total;       // rows (boxes) with at least one candidate above conf
@@ -298,20 +311,34 @@ __global__ __launch_bounds__(kPickThreads) void v5_pick_kernel(const V5Args a) {
     for (int i = tid; i < kHistBins; i += kPickThreads) hist[i] = 0;
     if (tid == 0) { s_nq = 0; s_count = 0; }
     __syncthreads();
-    for (int r = tid; r < a.nboxes; r += kPickThreads) {
+    // the row maxima of this thread stay in registers between the two passes (up to kRmRegs * 1024 boxes; the rest is
+    // read again), and all loads of a pass are issued before the first use
+    constexpr int kRmRegs = 32;
+    float rv[kRmRegs];
+#pragma unroll
+    for (int k = 0; k < kRmRegs; ++k) {
+        const int r = tid + k * kPickThreads;
+        rv[k] = r < a.nboxes ? rm[r] : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < kRmRegs; ++k)
+        if (rv[k] > a.conf) atomicAdd(&hist[score_bin(rv[k], base16)], 1u);
+    for (int r = tid + kRmRegs * kPickThreads; r < a.nboxes; r += kPickThreads) {
         const float v = rm[r];
         if (v > a.conf) atomicAdd(&hist[score_bin(v, base16)], 1u);
     }
     __syncthreads();
     unsigned total_rows;
     const unsigned row_bin = select_bin(hist, part, s_sel, (unsigned)a.max_nms, &total_rows);
-    for (int r = tid; r < a.nboxes; r += kPickThreads) {
-        const float v = rm[r];
+    auto enqueue = [&](int r, float v) {
         if (v > a.conf && score_bin(v, base16) >= row_bin) {
             const unsigned pos = atomicAdd(&s_nq, 1u);
             if (pos < (unsigned)kListCap) queue[pos] = (unsigned)r;
         }
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < kRmRegs; ++k) enqueue(tid + k * kPickThreads, rv[k]);
+    for (int r = tid + kRmRegs * kPickThreads; r < a.nboxes; r += kPickThreads) enqueue(r, rm[r]);
     for (int i = tid; i < kHistBins; i += kPickThreads) hist[i] = 0;
     __syncthreads();
     V5Meta& m = a.meta[img];
@@ -325,18 +352,35 @@ __global__ __launch_bounds__(kPickThreads) void v5_pick_kernel(const V5Args a) {
     // visit(row, cls, score) for every candidate of the queued rows
     auto for_candidates = [&](auto visit) {
         if (a.multi) {
+            // (row, class) pairs, consecutive threads on consecutive classes of a row; eight pairs per thread in
+            // flight, their loads issued before the first test
+            constexpr int U = 8;
             const unsigned npair = nq * (unsigned)a.nc;
-            for (unsigned p = tid; p < npair; p += kPickThreads) {
-                const unsigned q = p / (unsigned)a.nc;
-                const int c = (int)(p - q * (unsigned)a.nc);
-                const unsigned row = queue[q];
-                const float* pr = pimg + (size_t)row * a.no;
-                const float obj = pr[4];
-                if (!(obj > a.conf)) continue;
-                const float sc = pr[5 + c] * obj;
-                if (!(sc > a.conf)) continue;
-                if (a.class_mask && !a.class_mask[c]) continue;
-                visit(row, c, sc);
+            const float rnc = 1.0f / (float)a.nc;
+            for (unsigned p0 = tid; p0 < npair; p0 += kPickThreads * U) {
+                unsigned row[U];
+                int cls[U];
+                float obj[U], val[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned p = p0 + u * kPickThreads;
+                    const bool in = p < npair;
+                    // the float-reciprocal quotient is exact below 2^22: nq <= 4096 rows, so up to 1000 classes
+                    const unsigned q = !in ? 0u : a.nc <= 1000 ? (unsigned)div_small((int)p, a.nc, rnc) : p / (unsigned)a.nc;
+                    cls[u] = in ? (int)(p - q * (unsigned)a.nc) : 0;
+                    row[u] = queue[q];
+                    const float* pr = pimg + (size_t)row[u] * a.no;
+                    obj[u] = in ? pr[4] : 0.f;
+                    val[u] = in ? pr[5 + cls[u]] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (p0 + u * kPickThreads >= npair || !(obj[u] > a.conf)) continue;
+                    const float sc = val[u] * obj[u];
+                    if (!(sc > a.conf)) continue;
+                    if (a.class_mask && !a.class_mask[cls[u]]) continue;
+                    visit(row[u], cls[u], sc);
+                }
             }
         } else {
             for (unsigned q = tid; q < nq; q += kPickThreads) {
@@ -469,10 +513,12 @@ __global__ __launch_bounds__(256) void v5_rank_kernel(const V5Args a) {
     if (threadIdx.x == 0) m->ns = (unsigned)ns;
 }
 
-__global__ __launch_bounds__(256) void v5_nms_kernel(const V5Args a) {
+constexpr int kNmsThreads = 1024;
+__global__ __launch_bounds__(kNmsThreads) void v5_nms_kernel(const V5Args a) {
     __shared__ NmsShared sh;
     __shared__ u64 removed[kMaxNms / 64], kept[kMaxNms / 64];
     __shared__ int wbase[kMaxNms / 64 + 1];
+    __shared__ float4 lbox[kNmsLdsBoxes];   // the sorted boxes, when they fit: every chunk re-reads the later ones
     const int img = blockIdx.x;
     const V5Meta* m = a.meta + img;
     const int ns = (int)m->ns;
@@ -480,7 +526,13 @@ __global__ __launch_bounds__(256) void v5_nms_kernel(const V5Args a) {
     float* out = a.out_det + (size_t)img * a.max_det * 6;
     int count = 0;
     if (ns > 0) {
-        greedy_nms_block<false>(ns, a.iou, [&](int s) { return sbox[s]; }, sh, removed, kept);
+        if (ns <= kNmsLdsBoxes) {    // workgroup-uniform
+            for (int s = threadIdx.x; s < ns; s += kNmsThreads) lbox[s] = sbox[s];
+            __syncthreads();
+            greedy_nms_block<false, kNmsThreads>(ns, a.iou, [&](int s) { return lbox[s]; }, sh, removed, kept);
+        } else {
+            greedy_nms_block<false, kNmsThreads>(ns, a.iou, [&](int s) { return sbox[s]; }, sh, removed, kept);
+        }
         const int nwords = (ns + 63) >> 6;
         if (threadIdx.x == 0) {
             int acc = 0;
@@ -491,7 +543,7 @@ __global__ __launch_bounds__(256) void v5_nms_kernel(const V5Args a) {
         count = min(wbase[nwords], a.max_det);
         const u64* sorted = a.sorted + (size_t)img * kMaxNms;
         const float* pimg = a.pred + (size_t)img * a.nboxes * a.no;
-        for (int s = threadIdx.x; s < ns; s += 256) {
+        for (int s = threadIdx.x; s < ns; s += kNmsThreads) {
             const u64 kw = kept[s >> 6];
             if (!((kw >> (s & 63)) & 1ull)) continue;
             const int pos = wbase[s >> 6] + __popcll(kw & ((1ull << (s & 63)) - 1ull));
@@ -510,7 +562,7 @@ __global__ __launch_bounds__(256) void v5_nms_kernel(const V5Args a) {
             o[5] = (float)cls;
         }
     }
-    for (int e = count * 6 + threadIdx.x; e < a.max_det * 6; e += 256) out[e] = 0.f;
+    for (int e = count * 6 + threadIdx.x; e < a.max_det * 6; e += kNmsThreads) out[e] = 0.f;
     if (threadIdx.x == 0) a.out_count[img] = count;
 }
 
@@ -707,7 +759,7 @@ extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float c
     hipLaunchKernelGGL(v5_pick_kernel, dim3((unsigned)N), dim3(kPickThreads), 0, s, a);
     hipLaunchKernelGGL(v5_exact_select_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(v5_rank_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(v5_nms_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_nms_kernel, dim3((unsigned)N), dim3(kNmsThreads), 0, s, a);
     YDET_CHECK_LAUNCH("nms_v5 kernels");
     return YDET_OK;
 }
