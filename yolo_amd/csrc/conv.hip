@@ -109,10 +109,11 @@ __device__ __forceinline__ float activate(float v, int act, float slope) {
 }
 
 // Four consecutive output channels of one pixel: bias, residual (either order), activation, and the optional second
-// affine + activation (a BatchNorm + activation that follows a concatenation).  MODE is fixed per launch and resolved
-// once per kernel (bit 0: SiLU, else leaky with a.slope -- slope 1 is "no activation"; bit 1: second stage present),
-// so the 64 values a lane finishes run through straight-line code.  b4 / ps4 / pb4 point at the four channels' bias,
-// post-scale and post-shift (global memory or the tile's LDS copy).
+// affine + activation (a BatchNorm + activation that follows a concatenation).  MODE >= 0 fixes the variant at compile
+// time (bit 0: SiLU, else leaky with a.slope -- slope 1 is "no activation"; bit 1: second stage present; bit 2: the
+// residual goes in before the activation), so the 64 values a lane finishes run through straight-line code; MODE < 0
+// reads the variant from the arguments (the rarely used store paths, to keep the number of instantiations down).
+// b4 / ps4 / pb4 point at the four channels' bias, post-scale and post-shift (global memory or the tile's LDS copy).
 template <int MODE>
 __device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], const float* b4, const float* ps4,
                                         const float* pb4, const ConvArgs& a) {
@@ -120,20 +121,22 @@ __device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], cons
         const float4 b = *reinterpret_cast<const float4*>(b4);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    const bool before = a.res_mode == YDET_RES_BEFORE_ACT;
+    const bool silu = MODE >= 0 ? (MODE & 1) != 0 : a.act == YDET_ACT_SILU;
+    const bool post = MODE >= 0 ? (MODE & 2) != 0 : a.post_scale != nullptr;
+    const bool before = MODE >= 0 ? (MODE & 4) != 0 : a.res_mode == YDET_RES_BEFORE_ACT;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float x = v[e] + (before ? r[e] : 0.f);
-        if (MODE & 1) {
+        float x = before ? v[e] + r[e] : v[e];     // "after" and "none" share one path: r is zero without a residual
+        if (silu) {
             // x * sigmoid(x) on the hardware exp2 / reciprocal units (relative error ~1e-6, far inside the bf16 / 1e-3
             // bars): 5 instructions instead of ~25 with an IEEE division
             x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
         } else {
             x = x > 0.f ? x : x * a.slope;
         }
-        v[e] = x + (before ? 0.f : r[e]);
+        v[e] = before ? x : x + r[e];
     }
-    if (MODE & 2) {
+    if (post) {
         const float4 ps = *reinterpret_cast<const float4*>(ps4);
         const float4 pb = *reinterpret_cast<const float4*>(pb4);
         v[0] = activate(v[0] * ps.x + pb.x, a.post_act, a.post_slope);
@@ -143,14 +146,14 @@ __device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], cons
     }
 }
 
-// Calls f(std::integral_constant<int, MODE>) for the launch's epilogue mode.
+// Calls f(std::integral_constant<int, MODE>) for the launch's epilogue variant: the two common ones (leaky / SiLU,
+// residual absent or added last, no second stage) are compiled in, everything else takes the run-time form.
 template <typename F>
 __device__ __forceinline__ void with_epilogue_mode(const ConvArgs& a, F f) {
-    const int mode = (a.act == YDET_ACT_SILU ? 1 : 0) | (a.post_scale ? 2 : 0);
-    if (mode == 0) f(std::integral_constant<int, 0>{});
-    else if (mode == 1) f(std::integral_constant<int, 1>{});
-    else if (mode == 2) f(std::integral_constant<int, 2>{});
-    else f(std::integral_constant<int, 3>{});
+    const bool plain = a.post_scale == nullptr && a.res_mode != YDET_RES_BEFORE_ACT;
+    if (plain && a.act == YDET_ACT_SILU) f(std::integral_constant<int, 1>{});
+    else if (plain) f(std::integral_constant<int, 0>{});
+    else f(std::integral_constant<int, -1>{});
 }
 
 template <typename T>
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
-                    finish4<MODE>(v, r, b4, a.post_scale + co, a.post_shift + co, a);
+                    finish4<-1>(v, r, b4, a.post_scale + co, a.post_shift + co, a);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
@@ -749,9 +752,10 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         YDET_STAMP(25);
         return;
     }
-    with_epilogue_mode(a, [&](auto mode) {
+    if (a.lds_epilogue) {
+      with_epilogue_mode(a, [&](auto mode) {
         constexpr int MODE = decltype(mode)::value;
-        if (a.lds_epilogue) {
+        {
             constexpr int V = 16 / (int)sizeof(TOUT);       // channels per 16-byte piece
             constexpr int PIECES = BN / V;                  // pieces per pixel row of the tile
 #pragma unroll
@@ -759,6 +763,27 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                 __builtin_amdgcn_s_barrier();               // the ring / the previous pass is no longer read
                 asm volatile("" ::: "memory");
                 YDET_STAMP(20);
+                // bf16 residuals of the pass are fetched up front (one memory latency for all of them instead of one
+                // per four values); fp32 residuals would double the accumulator registers and stay inline
+                constexpr bool PREFETCH_RES = sizeof(TIN) == 2;
+                bf16x4 rr[PREFETCH_RES ? FM : 1][PREFETCH_RES ? FN : 1];
+                if constexpr (PREFETCH_RES) {
+                    if (a.res) {
+#pragma unroll
+                        for (int j = 0; j < FM; ++j) {
+                            const int pl = wm * WM + j * 16 + px;
+                            if (pl / PM != pass) continue;
+                            const long long m = m0 + pl;
+                            const char* rrow = a.res + ((size_t)(m < a.M ? m : 0) * a.res_ld + a.res_coff) * sizeof(TIN);
+#pragma unroll
+                            for (int i = 0; i < FN; ++i) {
+                                const int co = n0 + wn * WN + i * 16 + q * 4;
+                                rr[j][i] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                                if (m < a.M && co < a.Cout) rr[j][i] = *reinterpret_cast<const bf16x4*>(rrow + (size_t)co * sizeof(TIN));
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
                     const int pl = wm * WM + j * 16 + px;   // pixel inside the tile
@@ -772,7 +797,11 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                         const int co = n0 + cl;
                         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                         float r[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
+                        if constexpr (PREFETCH_RES) {
+                            if (a.res) { r[0] = (float)rr[j][i][0]; r[1] = (float)rr[j][i][1]; r[2] = (float)rr[j][i][2]; r[3] = (float)rr[j][i][3]; }
+                        } else {
+                            if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
+                        }
                         finish4<MODE>(v, r, cst + cl, cst + BN + cl, cst + 2 * BN + cl, a);
                         store4<TOUT>(lrow + cl * sizeof(TOUT), v);
                     }
@@ -794,8 +823,12 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                 }
             }
             YDET_STAMP(30);
-            return;
         }
+      });
+      return;
+    }
+    // output slices that rule out 16-byte pieces: element stores, the variant read at run time
+    {
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const long long m = m0 + wm * WM + j * 16 + px;
@@ -812,13 +845,13 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (rrow && co + e < a.Cout) r[e] = to_f32(reinterpret_cast<const TIN*>(rrow)[co + e]);
-                finish4<MODE>(v, r, cst + cl, cst + BN + cl, cst + 2 * BN + cl, a);
+                finish4<-1>(v, r, cst + cl, cst + BN + cl, cst + 2 * BN + cl, a);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (co + e < a.Cout) reinterpret_cast<TOUT*>(yrow)[co + e] = from_f32<TOUT>(v[e]);
             }
         }
-    });
+    }
 }
 
 template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
