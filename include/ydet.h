@@ -111,15 +111,15 @@ int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
  * slice [N, H/2, W/2, Cout], Cout <= 64.  bf16 weights / output only; x_ld, x_coff, res and post_* are unused. */
 int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
 
-/* A residual bottleneck with 32 channels throughout as ONE kernel: yolov5_official/modules.py:208-218,
- * `x + self.cv2(self.cv1(x))` with cv1 = Conv(32, 32, 1, 1) and cv2 = Conv(32, 32, 3, 1) (the bottleneck of the first C3
- * stage of yolov5s.yaml).  cv1 describes the 1x1 stage (x, w, bias, shape, activation; its y is not used: the
+/* A residual bottleneck with C = 32 or 64 channels throughout as ONE kernel: yolov5_official/modules.py:208-218,
+ * `x + self.cv2(self.cv1(x))` with cv1 = Conv(C, C, 1, 1) and cv2 = Conv(C, C, 3, 1) (the bottlenecks of the first two
+ * C3 stages of yolov5s.yaml).  cv1 describes the 1x1 stage (x, w, bias, shape, activation; its y is not used: the
  * intermediate map never leaves the chip), cv2 the 3x3 / stride 1 / pad 1 stage (w, bias, y; its x is not used).
  * cv2->res is NULL (no shortcut) or equal to cv1's input slice with res_mode = AFTER_ACT.  Both stages share one
  * activation; bf16 only.  The output slice must not overlap the input slice (a tile's halo is read while other
  * workgroups write their outputs).  Same bf16 intermediate and accumulation order as the two stages run through
  * ydet_conv2d_nhwc. */
-int ydet_bottleneck_c32(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, void* stream);
+int ydet_bottleneck_fused(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pooling / resampling / layout operators on NHWC slices.
@@ -275,7 +275,7 @@ typedef enum {
     YDET_OP_NHWC2NCHW = 8,     /* iarg3 = destination dtype */
     YDET_OP_FOCUS_CONV = 9,    /* conv: as ydet_focus_conv3x3_nchw; iarg3 = image dtype */
     YDET_OP_HEAD_DECODE = 10,  /* conv + head: as ydet_head_conv_decode */
-    YDET_OP_BOTTLENECK_C32 = 11 /* conv + conv2: as ydet_bottleneck_c32 */
+    YDET_OP_BOTTLENECK = 11 /* conv + conv2: as ydet_bottleneck_fused */
 } ydet_op_kind;
 
 typedef struct {
@@ -284,7 +284,7 @@ typedef struct {
     ydet_conv_desc conv;   /* YDET_OP_CONV, YDET_OP_FOCUS_CONV, YDET_OP_HEAD_DECODE */
     ydet_slice_desc slice; /* pooling / resampling / layout ops */
     ydet_head_desc head;   /* YDET_OP_HEAD_DECODE */
-    ydet_conv_desc conv2;  /* YDET_OP_BOTTLENECK_C32: the 3x3 stage */
+    ydet_conv_desc conv2;  /* YDET_OP_BOTTLENECK: the 3x3 stage */
 } ydet_op;
 
 int ydet_run_ops(const ydet_op* ops /* host */, int n_ops, void* stream);

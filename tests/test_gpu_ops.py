@@ -408,7 +408,8 @@ def test_focus_stem_fused(shape, cout, src):
 
 
 # ---- 32-channel bottleneck as one kernel ---------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(2, 32, 16, 64), (1, 32, 13, 37), (3, 32, 40, 40), (1, 32, 5, 3)])
+@pytest.mark.parametrize("shape", [(2, 32, 16, 64), (1, 32, 13, 37), (3, 32, 40, 40), (1, 32, 5, 3),
+                                   (2, 64, 16, 32), (1, 64, 13, 37), (3, 64, 40, 40), (1, 64, 5, 3)])
 @pytest.mark.parametrize("add", [True, False])
 @pytest.mark.parametrize("act", ["silu", "leaky"])
 def test_bottleneck_c32_fused(shape, add, act):
@@ -417,7 +418,7 @@ def test_bottleneck_c32_fused(shape, add, act):
     accumulation order; the epilogues may contract multiply-adds differently, so the bar is one bf16 ulp)."""
     from yolo_amd.yolov5_official.modules import Bottleneck
     from yolo_amd.synthetic import init_deterministic
-    m = Bottleneck(32, 32, shortcut=add, e=1.0)
+    m = Bottleneck(shape[1], shape[1], shortcut=add, e=1.0)
     if act == "leaky":
         m.cv1.act = m.cv2.act = nn.LeakyReLU(0.1)
     init_deterministic(m, seed=5)
@@ -458,7 +459,7 @@ def test_bottleneck_c32_rejects_in_place():
         d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = 1, 8, 8, 32, 32, k, k, 1, p, 8, 8
         d.x_ld = d.y_ld = 32
         d.kp, d.cout_pad, d.act, d.in_dtype, d.out_dtype = kp, 128, _ffi.ACT_SILU, _ffi.BF16, _ffi.BF16
-    assert lib.ydet_bottleneck_c32(c1, c2, None) == -1 and b"overlaps" in lib.ydet_last_error()
+    assert lib.ydet_bottleneck_fused(c1, c2, None) == -1 and b"overlaps" in lib.ydet_last_error()
 
 
 @pytest.mark.parametrize("c0,c1,cin,k", [(32, 32, 64, 1), (64, 24, 32, 3), (8, 128, 96, 1)])

@@ -138,8 +138,9 @@ def test_planner_v5s_on_cpu():
     plan = g.finalize()
     kinds = [k for k, _ in g.ops]
     # 62 convolutions: 8 C3 (cv1, cv2) pairs fused, the first one fused with the Focus slicing and the NCHW edge, the
-    # 32-channel bottleneck of the first C3 (1x1 + 3x3) one kernel, the three prediction convs decode in place
-    assert kinds[0] == "focus_conv" and kinds.count("conv") == 48 and kinds.count("bottleneck") == 1
+    # 32- and 64-channel bottlenecks (1x1 + 3x3: one in the first C3, three in the second, one in the last neck C3 at
+    # 80 x 80) one kernel each, the three prediction convs decode in place
+    assert kinds[0] == "focus_conv" and kinds.count("conv") == 40 and kinds.count("bottleneck") == 5
     assert kinds.count("head_decode") == 3 and "copy" not in kinds
     assert kinds.count("spp") == 1 and kinds.count("upsample") == 2
     bn = [op for op in plan.ops if op.kind == 11][0]          # reads cv1's own buffer, writes the first half of the concat

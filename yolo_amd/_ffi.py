@@ -13,7 +13,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
- OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK_C32) = range(12)
+ OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK) = range(12)
 MAX_ANCHORS = 8
 ABI_VERSION = 6   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
@@ -89,7 +89,7 @@ SYMBOLS = {
     "ydet_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "ydet_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "ydet_head_conv_decode": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(HeadDesc), C.c_void_p]),
-    "ydet_bottleneck_c32": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
+    "ydet_bottleneck_fused": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
     "ydet_decode_v5": (C.c_int, [C.POINTER(V5Level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "ydet_decode_v2v3": (C.c_int, [C.POINTER(FALevel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -1,4 +1,4 @@
-// A 32-channel residual bottleneck as one kernel: y = x + act(conv3x3(act(conv1x1(x)))) (yolov5_official/modules.py:208-218
+// A 32- or 64-channel residual bottleneck as one kernel (the 32-channel form first): y = x + act(conv3x3(act(conv1x1(x)))) (yolov5_official/modules.py:208-218
 // with c1 = c2 = c_ = 32, the first C3 stage of YOLOv5s).  Run as two convolutions this pair is bound by L2 traffic
 // (the 3x3 tap walk re-reads every input pixel nine times) and by the round trip of the intermediate map through HBM;
 // here a workgroup keeps the input patch and the intermediate patch of an 8 x 32 output tile in LDS.
@@ -149,36 +149,196 @@ __global__ __launch_bounds__(256) void bottleneck_c32_kernel(const BneckArgs a) 
     }
 }
 
+
+// ---- 64 channels throughout -----------------------------------------------------------------------------------------
+// Same scheme for the 64-channel bottlenecks (the second C3 stage of YOLOv5s at 80 x 80), where the weights no longer
+// fit one wave's registers: the four waves split the OUTPUT CHANNELS (16 each: 18 A fragments of the 3x3 stage and 2
+// of the 1x1 stage per lane) and every wave walks all pixel groups of an 8 x 16 output tile.  Patches at a 144-byte
+// pixel pitch (128 of data + 16: eight consecutive pixels' 16-byte reads cover all banks once).  The finished tile
+// goes through LDS once more so that global stores are 16-byte pieces of whole pixels.
+namespace c64 {
+constexpr int TH = 8, TW = 16;
+constexpr int PH = TH + 2, PW = TW + 2;
+constexpr int NPIX = PH * PW;                   // 180 patch pixels
+constexpr int NGRP = (NPIX + 15) / 16;          // 12 groups for the 1x1 stage (the last one reads 12 rows of slack)
+constexpr int PITCH = 144;
+constexpr int PATCH_BYTES = NPIX * PITCH;       // 25920
+constexpr int SLACK = (NGRP * 16 - NPIX) * PITCH;
+constexpr int NLOAD = (NPIX * 8 + 255) / 256;   // 16-byte pieces of the input patch per thread
+}  // namespace c64
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_c64_kernel(const BneckArgs a) {
+    constexpr int TH = c64::TH, TW = c64::TW, PW = c64::PW, NPIX = c64::NPIX, NGRP = c64::NGRP, PITCH = c64::PITCH;
+    constexpr int PATCH_BYTES = c64::PATCH_BYTES, SLACK = c64::SLACK, NLOAD = c64::NLOAD;
+    // xs | ts | slack: the 1x1 stage's last group reads past xs into ts (its results are dropped), ts likewise into slack
+    __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES + SLACK];
+    char* xs = smem;
+    char* ts = smem + PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, q = lane >> 4;
+    const bool silu = a.act == YDET_ACT_SILU;
+    const float slope = a.act == YDET_ACT_LEAKY ? a.slope : 1.0f;
+
+    // A fragments of this wave's 16 output channels: row r = lane & 15 is channel 16 * wave + r, k chunk q
+    const int co_a = wave * 16 + (lane & 15);
+    bf16x8 w1f[2], w2f[9][2];
+#pragma unroll
+    for (int kh2 = 0; kh2 < 2; ++kh2) {
+        w1f[kh2] = *reinterpret_cast<const bf16x8*>(a.w1 + ((size_t)co_a * a.kp1 + kh2 * 32 + q * 8) * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            w2f[t][kh2] = *reinterpret_cast<const bf16x8*>(a.w2 + ((size_t)co_a * a.kp2 + t * 64 + kh2 * 32 + q * 8) * 2);
+    }
+    // D rows of a lane: channels 16 * wave + 4 q .. + 3
+    const int co_d = wave * 16 + q * 4;
+    float b1v[4], b2v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { b1v[e] = a.b1[co_d + e]; b2v[e] = a.b2[co_d + e]; }
+
+    uint4 pre[NLOAD];
+    auto fetch = [&](int tile) {
+        const int n = tile / a.tiles_per_img, r = tile - n * a.tiles_per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * 256, p = idx >> 3, ch = idx & 7;
+            const int pr = p / PW, pc = p - pr * PW;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = p < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            pre[k] = uint4{0, 0, 0, 0};
+            if (ok)
+                pre[k] = *reinterpret_cast<const uint4*>(a.x + ((((size_t)n * a.H + iy) * a.W + ix) * a.x_ld + a.x_coff + ch * 8) * 2);
+        }
+    };
+
+    // two waves per SIMD (the A fragments alone are 80 registers): the next tile's patch is fetched into registers
+    // while this one is computed
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) fetch(tile);
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        const int n = tile / a.tiles_per_img, r = tile - n * a.tiles_per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        // ---- patch -> LDS ---------------------------------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * 256, p = idx >> 3, ch = idx & 7;
+            if (p < NPIX) *reinterpret_cast<uint4*>(xs + p * PITCH + ch * 16) = pre[k];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.n_tiles) fetch(tile + gridDim.x);
+        // ---- 1x1 over the whole patch: this wave's 16 channels of every patch pixel -> ts -------------------------
+        static_assert(NGRP % 4 == 0, "four pixel groups at a time");
+#pragma unroll
+        for (int g0 = 0; g0 < NGRP; g0 += 4) {     // four groups in flight: their LDS reads, then their MFMAs
+            bf16x8 x0[4], x1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = (g0 + u) * 16 + px;
+                x0[u] = *reinterpret_cast<const bf16x8*>(xs + p * PITCH + q * 16);
+                x1[u] = *reinterpret_cast<const bf16x8*>(xs + p * PITCH + 64 + q * 16);
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[0], x0[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[1], x1[u], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = (g0 + u) * 16 + px;
+                const int pr = p / PW, pc = p - pr * PW;
+                const bool in = p < NPIX && (unsigned)(oy0 - 1 + pr) < (unsigned)a.H && (unsigned)(ox0 - 1 + pc) < (unsigned)a.W;
+                bf16x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (__bf16)(in ? act_fn(acc[u][e] + b1v[e], silu, slope) : 0.f);
+                if (p < NPIX) *reinterpret_cast<bf16x4*>(ts + p * PITCH + co_d * 2) = t;
+            }
+        }
+        __syncthreads();
+        // ---- 3x3 over ts: this wave's 16 channels of all 8 rows (groups of 16 pixels), four groups at a time --------
+        // (a finished value replaces the residual it was added to: only this lane reads that spot of xs)
+#pragma unroll
+        for (int gs = 0; gs < TH; gs += 4) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int kh2 = 0; kh2 < 2; ++kh2) {
+                    bf16x8 tb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        tb[u] = *reinterpret_cast<const bf16x8*>(ts + ((gs + u + t / 3) * PW + t % 3 + px) * PITCH + kh2 * 64 + q * 16);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t][kh2], tb[u], acc[u], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = gs + u;
+                char* spot = xs + ((row + 1) * PW + 1 + px) * PITCH + co_d * 2;
+                bf16x4 res, o;
+                if (a.add) res = *reinterpret_cast<const bf16x4*>(spot);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = act_fn(acc[u][e] + b2v[e], silu, slope);
+                    if (a.add) v += (float)res[e];
+                    o[e] = (__bf16)v;
+                }
+                *reinterpret_cast<bf16x4*>(spot) = o;
+            }
+        }
+        __syncthreads();   // the finished tile sits at the centre pixels of xs
+#pragma unroll
+        for (int k = 0; k < TH * TW * 8 / 256; ++k) {
+            const int idx = tid + k * 256, p = idx >> 3, ch = idx & 7;
+            const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            const uint4 v = *reinterpret_cast<const uint4*>(xs + ((p / TW + 1) * PW + 1 + p % TW) * PITCH + ch * 16);
+            if (oy < a.H && ox < a.W)
+                *reinterpret_cast<uint4*>(a.y + ((((size_t)n * a.H + oy) * a.W + ox) * a.y_ld + a.y_coff + ch * 8) * 2) = v;
+        }
+        __syncthreads();   // xs / ts are rewritten by the next tile
+    }
+}
+
 }  // namespace
 
-int ydet_launch_bottleneck_c32(const ydet_conv_desc* c1, const ydet_conv_desc* c2, hipStream_t stream) {
+int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, hipStream_t stream) {
     using namespace ydet;
-    YDET_CHECK_ARG(c1 && c2, "bottleneck_c32: null descriptor");
-    YDET_CHECK_ARG(c1->x && c1->w && c1->bias && c2->w && c2->bias && c2->y, "bottleneck_c32: null x/w/bias/y pointer");
+    YDET_CHECK_ARG(c1 && c2, "bottleneck_fused: null descriptor");
+    YDET_CHECK_ARG(c1->x && c1->w && c1->bias && c2->w && c2->bias && c2->y, "bottleneck_fused: null x/w/bias/y pointer");
     YDET_CHECK_ARG(c1->in_dtype == YDET_BF16 && c1->out_dtype == YDET_BF16 && c2->in_dtype == YDET_BF16 &&
-                       c2->out_dtype == YDET_BF16, "bottleneck_c32: bf16 only");
-    YDET_CHECK_ARG(c1->Cin == 32 && c1->Cout == 32 && c2->Cin == 32 && c2->Cout == 32, "bottleneck_c32: 32 channels throughout");
+                       c2->out_dtype == YDET_BF16, "bottleneck_fused: bf16 only");
+    const int C = c1->Cin;
+    YDET_CHECK_ARG((C == 32 || C == 64) && c1->Cout == C && c2->Cin == C && c2->Cout == C,
+                   "bottleneck_fused: 32 or 64 channels throughout");
     YDET_CHECK_ARG(c1->KH == 1 && c1->KW == 1 && c1->stride == 1 && c1->pad == 0 && c2->KH == 3 && c2->KW == 3 &&
-                       c2->stride == 1 && c2->pad == 1, "bottleneck_c32: a 1x1 followed by a 3x3 / stride 1 / pad 1");
+                       c2->stride == 1 && c2->pad == 1, "bottleneck_fused: a 1x1 followed by a 3x3 / stride 1 / pad 1");
     YDET_CHECK_ARG(c1->N > 0 && c1->H > 0 && c1->W > 0 && c2->N == c1->N && c2->H == c1->H && c2->W == c1->W &&
-                       c2->Ho == c1->H && c2->Wo == c1->W, "bottleneck_c32: shapes of the two stages differ");
-    YDET_CHECK_ARG(c1->kp == 32 && c2->kp == 288 && c1->cout_pad >= 32 && c2->cout_pad >= 32, "bottleneck_c32: kp %d / %d",
+                       c2->Ho == c1->H && c2->Wo == c1->W, "bottleneck_fused: shapes of the two stages differ");
+    YDET_CHECK_ARG(c1->kp == C && c2->kp == 9 * C && c1->cout_pad >= C && c2->cout_pad >= C, "bottleneck_fused: kp %d / %d",
                    c1->kp, c2->kp);
     YDET_CHECK_ARG(c1->act == c2->act && c1->slope == c2->slope && c1->act >= 0 && c1->act <= 2,
-                   "bottleneck_c32: both stages share one activation");
-    YDET_CHECK_ARG(c1->res == nullptr && c1->post_scale == nullptr && c2->post_scale == nullptr,
-                   "bottleneck_c32: no residual on the first stage, no second epilogue stage");
-    YDET_CHECK_ARG(c1->x_ld % 8 == 0 && c1->x_coff % 8 == 0 && c1->x_coff >= 0 && c1->x_coff + 32 <= c1->x_ld &&
-                       c2->y_ld % 8 == 0 && c2->y_coff % 8 == 0 && c2->y_coff >= 0 && c2->y_coff + 32 <= c2->y_ld,
-                   "bottleneck_c32: channel slices must be 8-aligned and inside their rows");
+                   "bottleneck_fused: both stages share one activation");
+    YDET_CHECK_ARG(c1->res == nullptr && c1->post_scale == nullptr && c2->post_scale == nullptr && c1->y2 == nullptr &&
+                       c2->y2 == nullptr, "bottleneck_fused: no residual on the first stage, no second stage or destination");
+    YDET_CHECK_ARG(c1->x_ld % 8 == 0 && c1->x_coff % 8 == 0 && c1->x_coff >= 0 && c1->x_coff + C <= c1->x_ld &&
+                       c2->y_ld % 8 == 0 && c2->y_coff % 8 == 0 && c2->y_coff >= 0 && c2->y_coff + C <= c2->y_ld,
+                   "bottleneck_fused: channel slices must be 8-aligned and inside their rows");
+    YDET_CHECK_ARG(((uintptr_t)c1->x & 15) == 0 && ((uintptr_t)c2->y & 15) == 0 && ((uintptr_t)c1->w & 15) == 0 &&
+                       ((uintptr_t)c2->w & 15) == 0, "bottleneck_fused: pointers must be 16-byte aligned");
     const bool add = c2->res != nullptr;
     if (add)
         YDET_CHECK_ARG(c2->res == c1->x && c2->res_ld == c1->x_ld && c2->res_coff == c1->x_coff &&
-                           c2->res_mode == YDET_RES_AFTER_ACT, "bottleneck_c32: the residual is the block's own input, added last");
+                           c2->res_mode == YDET_RES_AFTER_ACT, "bottleneck_fused: the residual is the block's own input, added last");
     // the halo of a tile is read while other workgroups write their outputs: in-place operation would race
     const bool same_buf = c2->y == c1->x && c2->y_ld == c1->x_ld;
-    YDET_CHECK_ARG(!same_buf || c2->y_coff + 32 <= c1->x_coff || c1->x_coff + 32 <= c2->y_coff,
-                   "bottleneck_c32: output slice overlaps the input slice");
+    YDET_CHECK_ARG(!same_buf || c2->y_coff + C <= c1->x_coff || c1->x_coff + C <= c2->y_coff,
+                   "bottleneck_fused: output slice overlaps the input slice");
     BneckArgs a;
     a.x = (const char*)c1->x; a.y = (char*)c2->y;
     a.w1 = (const char*)c1->w; a.b1 = c1->bias; a.w2 = (const char*)c2->w; a.b2 = c2->bias;
@@ -186,20 +346,26 @@ int ydet_launch_bottleneck_c32(const ydet_conv_desc* c1, const ydet_conv_desc* c
     a.x_ld = c1->x_ld; a.x_coff = c1->x_coff; a.y_ld = c2->y_ld; a.y_coff = c2->y_coff;
     a.kp1 = c1->kp; a.kp2 = c2->kp;
     a.act = c1->act; a.slope = c1->slope; a.add = add ? 1 : 0;
-    a.tiles_x = (a.W + TW - 1) / TW;
-    const long long tiles_y = (a.H + TH - 1) / TH;
+    const int tw = C == 32 ? TW : c64::TW, th = C == 32 ? TH : c64::TH;
+    a.tiles_x = (a.W + tw - 1) / tw;
+    const long long tiles_y = (a.H + th - 1) / th;
     const long long per_img = tiles_y * a.tiles_x, n_tiles = per_img * a.N;
-    YDET_CHECK_ARG(n_tiles < (1ll << 30), "bottleneck_c32: %lld tiles", n_tiles);
+    YDET_CHECK_ARG(n_tiles < (1ll << 30), "bottleneck_fused: %lld tiles", n_tiles);
     a.tiles_per_img = (int)per_img; a.n_tiles = (int)n_tiles;
-    // a few tiles per workgroup amortise the weight fetch; at least two rounds of workgroups keep every CU busy
-    long long grid = n_tiles;
-    if (grid > 2048) grid = (n_tiles + 3) / 4 > 2048 ? (n_tiles + 3) / 4 : 2048;
-    hipLaunchKernelGGL(bottleneck_c32_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
-    YDET_CHECK_LAUNCH("bottleneck_c32_kernel");
+    // Both kernels hold two workgroups per CU (registers): exactly that many workgroups walk over the tiles, so the
+    // weights are fetched once per resident workgroup (measured best among 1x, 2x, 3x, 4x the CU count and one
+    // workgroup per one to four tiles).
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const long long grid = n_tiles < 2LL * cus ? n_tiles : 2LL * cus;
+    if (C == 32) hipLaunchKernelGGL(bottleneck_c32_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(bottleneck_c64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    YDET_CHECK_LAUNCH("bottleneck kernel");
     return YDET_OK;
 }
 
-extern "C" int ydet_bottleneck_c32(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, void* stream) {
+extern "C" int ydet_bottleneck_fused(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, void* stream) {
     ydet::clear_error();
-    return ydet_launch_bottleneck_c32(cv1, cv2, ydet::as_stream(stream));
+    return ydet_launch_bottleneck(cv1, cv2, ydet::as_stream(stream));
 }

@@ -240,23 +240,24 @@ class Graph:
 
     def bottleneck(self, x, cv1, cv2, act=_ffi.ACT_NONE, slope=0.0, add=True, out=None):
         """x + cv2(cv1(x)) (or cv2(cv1(x)) without `add`) for cv1 = (1x1 conv, bn), cv2 = (3x3 conv, bn) sharing one
-        activation.  One fused kernel when every channel count is 32 on the bf16 path and `out` does not alias `x`
+        activation.  One fused kernel when every channel count is 32 (or 64) on the bf16 path and `out` does not alias `x`
         (the intermediate map then never exists in HBM); otherwise two convolutions."""
         (c1, bn1), (c2, bn2) = cv1, cv2
         geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups)
-        fused = (self.dt == _ffi.BF16 and x.C == 32 and c1.out_channels == 32 and c2.out_channels == 32
+        Cc = x.C
+        fused = (self.dt == _ffi.BF16 and Cc in (32, 64) and c1.out_channels == Cc and c2.out_channels == Cc
                  and geom(c1) == (1, 1, 0, 1) and geom(c2) == (3, 1, 1, 1) and x.dtype == _ffi.BF16
-                 and (out is None or out.resolve()[0] is not x.resolve()[0] or out.resolve()[1] + 32 <= x.resolve()[1]
-                      or x.resolve()[1] + 32 <= out.resolve()[1]))
+                 and (out is None or out.resolve()[0] is not x.resolve()[0] or out.resolve()[1] + Cc <= x.resolve()[1]
+                      or x.resolve()[1] + Cc <= out.resolve()[1]))
         if not fused:
             t = self.conv(x, c1, bn1, act=act, slope=slope)
             return self.conv(t, c2, bn2, act=act, slope=slope, res=x if add else None, res_mode=_ffi.RES_AFTER_ACT, out=out)
-        pc1 = pack_conv(c1, bn1, None, cin_phys=32, dtype=self.dt, device=self.device)
-        pc2 = pack_conv(c2, bn2, None, cin_phys=32, dtype=self.dt, device=self.device)
+        pc1 = pack_conv(c1, bn1, None, cin_phys=Cc, dtype=self.dt, device=self.device)
+        pc2 = pack_conv(c2, bn2, None, cin_phys=Cc, dtype=self.dt, device=self.device)
         self.keep += [pc1, pc2]
         if out is None:
-            out = self.new(x.N, x.H, x.W, 32)
-        assert (out.N, out.H, out.W, out.C, out.dtype) == (x.N, x.H, x.W, 32, _ffi.BF16), "bottleneck output shape mismatch"
+            out = self.new(x.N, x.H, x.W, Cc)
+        assert (out.N, out.H, out.W, out.C, out.dtype) == (x.N, x.H, x.W, Cc, _ffi.BF16), "bottleneck output shape mismatch"
         common = dict(x=x, y=out, act=act, slope=float(slope), post=None)
         self.ops.append(("bottleneck", dict(
             x=x, y=out, add=bool(add), pc=pc1, pc2=pc2,
@@ -390,7 +391,7 @@ class Plan:
             assert not a["x"].resolve()[0].external and not a["y"].resolve()[0].external
             self._fill_conv(op, i, a["cv1"], arena, record)
             self._fill_conv(op, i, a["cv2"], arena, record, d=op.conv2)
-            op.kind = _ffi.OP_BOTTLENECK_C32
+            op.kind = _ffi.OP_BOTTLENECK
         elif kind == "head_decode":
             self._fill_conv(op, i, a, arena, record)
             op.kind = _ffi.OP_HEAD_DECODE
@@ -635,8 +636,9 @@ def _op_info(kind, a):
     if kind == "bottleneck":
         x, y = a["x"], a["y"]
         px = y.N * y.H * y.W
-        return dict(kind="conv", label="conv_bottleneck_c32", flops=2.0 * px * 32 * 32 * 10,
-                    bytes=px * 32 * 2 * 2 + (32 * 32 + 32 * 288) * 2, shape=(x.N, x.H, x.W, 32, 32, 3, 1))
+        Cc = x.C
+        return dict(kind="conv", label=f"conv_bottleneck_c{Cc}", flops=2.0 * px * Cc * Cc * 10,
+                    bytes=px * Cc * 2 * 2 + 10 * Cc * Cc * 2, shape=(x.N, x.H, x.W, Cc, Cc, 3, 1))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
         return dict(kind="conv", label="conv_focus3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,

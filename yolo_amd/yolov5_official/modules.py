@@ -138,8 +138,8 @@ class C3(nn.Module):
             # cv1 and cv2 read the same input: one convolution writes [cv1(x) | cv2(x)] straight into the concat buffer;
             # the bottleneck chain then updates the first half in place (its residual is read by the thread that
             # overwrites it), so the concat never exists as an operation.
-            if c_ == 32 and g.dt == _ffi.BF16 and x.C % 32 == 0:
-                # 32-channel bottlenecks run as one kernel that must not work in place (it reads a halo): the sibling
+            if c_ in (32, 64) and g.dt == _ffi.BF16 and x.C % 32 == 0:
+                # 32- and 64-channel bottlenecks run as one kernel that must not work in place (it reads a halo): the sibling
                 # conv sends cv1(x) to a buffer of its own and cv2(x) to what becomes the second half of the concat
                 # buffer; the last bottleneck's output becomes the first half
                 _, (y, y2) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1, separate=True)
