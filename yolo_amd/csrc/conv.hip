@@ -644,7 +644,8 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 #else
                 if (m < a.M && co < a.cout_store)
 #endif
-                    *reinterpret_cast<float4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(float)) = piece_v[k];
+                    __builtin_nontemporal_store(f32x4{piece_v[k].x, piece_v[k].y, piece_v[k].z, piece_v[k].w},
+                                                reinterpret_cast<f32x4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(float)));
             }
         }
         __syncthreads();
@@ -735,7 +736,8 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                             if (v[u].x != 12345.678f) continue;
 #endif
                             const int an = div_small(k, per4, rper4);
-                            *reinterpret_cast<float4*>(zb + (size_t)(unsigned)(an * an_step + (k - an * per4) * 4)) = v[u];
+                            __builtin_nontemporal_store(f32x4{v[u].x, v[u].y, v[u].z, v[u].w},
+                                                        reinterpret_cast<f32x4*>(zb + (size_t)(unsigned)(an * an_step + (k - an * per4) * 4)));
                         }
                     }
                 }
