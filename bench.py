@@ -47,9 +47,14 @@ def main():
     ap.add_argument("--split", type=int, default=1, choices=[1, 2, 4],
                     help="run the forward pass as this many side-by-side launch lists over slices of the batch; with a "
                          "split the per-kernel events are taken in a second, unsplit loop outside the timed region")
-    ap.add_argument("--event-every", type=int, default=5,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="per-op events (kernel durations for the roofline object) are recorded on every E-th timed "
-                         "step: an event costs about 3 us of stream time, 57 of them per step are 5 %% of it")
+                         "step: an event costs 2-3 us of stream time, 55 of them per step are 5 %% of it, and "
+                         "such a step runs alone on the GPU (it drains the pipeline of batches)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches are issued round-robin on this many HIP streams (each with its own plan / activation "
+                         "arena), so the tail of one batch's kernels and its small-grid NMS overlap the next batch; the "
+                         "steps that carry per-op events run alone")
     args = ap.parse_args()
 
     import yolo_amd
@@ -61,7 +66,7 @@ def main():
     rank, world, local = ydist.init_from_env("cuda")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local if local < torch.cuda.device_count() else 0)   # (fewer GPUs than ranks: rehearsal only)
     torch.cuda.set_device(dev)
     lib = _ffi.lib()
 
@@ -71,36 +76,68 @@ def main():
     init_deterministic(model, seed=0, head_convs=list(model.model[-1].m))
     model = model.to(dev).eval()
     x = images(args.batch, args.size, seed=100 + rank).to(dev)
-    pinned_det = torch.empty(args.batch, 300, 6, pin_memory=True)
-    pinned_cnt = torch.empty(args.batch, dtype=torch.int32, pin_memory=True)
+    S = max(1, args.streams) if args.split == 1 else 1
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    pinned_det = [torch.empty(args.batch, 300, 6, pin_memory=True) for _ in range(S)]
+    pinned_cnt = [torch.empty(args.batch, dtype=torch.int32, pin_memory=True) for _ in range(S)]
 
     plan_holder = {}
 
-    def step(timer=None, mark=0, ev=None):
-        compute = engine.compute_dtype_for(model)
-        key = (tuple(x.shape), compute, x.device.index)
-        plan = model._plans().get(key, lambda: _build(model, x, compute))
-        plan_holder["plan"] = plan
-        outs = plan.run(x, timer=timer, first_mark=mark)
-        det_head = model.model[-1]
-        z, _ = det_head.finish(outs)
-        if ev is not None:
-            ev[1].record()
-        det, cnt = non_max_suppression_padded(z, 0.001, 0.6, multi_label=True)
-        if ev is not None:
-            ev[2].record()
-        pinned_det.copy_(det, non_blocking=True)
-        pinned_cnt.copy_(cnt, non_blocking=True)
+    def step(si=0, timer=None, mark=0, ev=None):
+        """One batch, start to finish, on stream si (the plan cache hands every stream its own plan)."""
+        with torch.cuda.stream(streams[si]):
+            compute = engine.compute_dtype_for(model)
+            key = (tuple(x.shape), compute, x.device.index)
+            plan = model._plans().get(key, lambda: _build(model, x, compute))
+            plan_holder["plan"] = plan
+            outs = plan.run(x, timer=timer, first_mark=mark)
+            det_head = model.model[-1]
+            z, _ = det_head.finish(outs)
+            if ev is not None:
+                ev[1].record()
+            det, cnt = non_max_suppression_padded(z, 0.001, 0.6, multi_label=True)
+            if ev is not None:
+                ev[2].record()
+            pinned_det[si].copy_(det, non_blocking=True)
+            pinned_cnt[si].copy_(cnt, non_blocking=True)
         return cnt
+
+    def step_alone(*a, **k):
+        """A step on stream 0 with nothing else on the GPU: the other streams are drained before and held after."""
+        for o in streams[1:]:
+            streams[0].wait_stream(o)
+        r = step(0, *a, **k)
+        for o in streams[1:]:
+            o.wait_stream(streams[0])
+        return r
 
     def _build(m, xx, compute):
         return engine.build_plan(xx.device, compute, xx.shape[0], lambda g, n: m._lower(g, n, *xx.shape[1:]))
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+        for k in range(max(args.warmup, S)):
+            step(k % S)
         torch.cuda.synchronize()
         n_ops = len(plan_holder["plan"].ops)
+        # What an event adds to the stream, measured before the timed region: the same step alone with and without
+        # its events (back-to-back events overstate it: a kernel in between hides part of an event's processing).
+        ncal = 9
+        cal_t = lib.ydet_timer_create(n_ops + 1)
+        cal_ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        cal_m = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ncal + 1)]
+        with torch.cuda.stream(streams[0]):
+            for i in range(ncal):
+                cal_m[2 * i].record()
+                step(0)
+                cal_m[2 * i + 1].record()
+                step(0, cal_t, 0, cal_ev)
+            cal_m[2 * ncal].record()
+        torch.cuda.synchronize()
+        diffs = sorted(cal_m[2 * i + 1].elapsed_time(cal_m[2 * i + 2]) - cal_m[2 * i].elapsed_time(cal_m[2 * i + 1])
+                       for i in range(ncal))
+        lib.ydet_timer_destroy(cal_t)
+        event_ms = max(diffs[ncal // 2] / (n_ops + 3), 0.0)      # median over the pairs
+        event_src = "a step alone with its events minus the same step without, per event (median of 9 pairs before the timed region)"
         sampled = [k for k in range(args.steps) if k % max(args.event_every, 1) == 0]   # steps that carry events
         n_ev = len(sampled)
         timer = lib.ydet_timer_create(n_ev * (n_ops + 1))
@@ -113,15 +150,14 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         split = plan_holder["plan"].R > 1
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # step boundaries
+        turn = 0
         for k in range(args.steps):
-            marks[k].record()
             if split or k not in sampled:
-                step()
+                step(turn % S)
+                turn += 1
             else:
                 j = sampled.index(k)
-                step(timer, j * (n_ops + 1), evs[j])
-        marks[args.steps].record()
+                step_alone(timer, j * (n_ops + 1), evs[j])
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -132,36 +168,17 @@ def main():
             step()
             torch.cuda.synchronize()
             for j in range(n_ev):
-                step(timer, j * (n_ops + 1), evs[j])
+                step(0, timer, j * (n_ops + 1), evs[j])
             torch.cuda.synchronize()
 
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        on_gpu = torch.distributed.get_backend() == "nccl"
+        t = torch.tensor([elapsed], device=dev if on_gpu else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- per-kernel device times from the events recorded during the timed steps ----------------------
-    # An interval between two events holds one kernel plus the events' own cost; that cost is measured on the same
-    # stream (50 events back to back, nothing between them) and taken off every interval.
-    ncal = 50
-    cal = lib.ydet_timer_create(ncal)
-    for i in range(ncal):
-        _ffi.check(lib.ydet_run_ops_timed(None, 0, _ffi.current_stream(), cal, i), "ydet_run_ops_timed")
-    torch.cuda.synchronize()
-    gaps = (ctypes.c_float * (ncal - 1))()
-    _ffi.check(lib.ydet_timer_elapsed(cal, 0, ncal - 1, gaps), "ydet_timer_elapsed")
-    lib.ydet_timer_destroy(cal)
-    event_ms = sorted(gaps)[(ncal - 1) // 2]
-    event_src = "median gap of 50 back-to-back events"
-    # Better when the timed region has steps with and without events: what an event really adds to the stream is the
-    # difference of their mean durations, spread over the events of a step (back-to-back events overstate it, a
-    # kernel in between hides part of the event's processing).
-    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
-    plain = [step_ms[k] for k in range(args.steps) if k not in sampled]
-    if not split and plain and sampled:
-        with_ev = [step_ms[k] for k in sampled]
-        event_ms = max((sum(with_ev) / len(with_ev) - sum(plain) / len(plain)) / (n_ops + 4), 0.0)
-        event_src = "mean duration of timed steps with events minus without, per event"
+    # An interval between two events holds one kernel plus the events' own cost, which is taken off (event_ms above).
     plan = plan_holder["plan"]
     per_label = {}
     buf = (ctypes.c_float * n_ops)()
@@ -226,6 +243,7 @@ def main():
         "config": {"workload": f"YOLOv5s (yolov5_official/model.py) {args.size}x{args.size}, batch {args.batch} per GPU, "
                                "forward + Detect decode + NMS (conf 0.001, iou 0.6, multi_label, max_det 300)",
                    "images_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}", "batch_split": args.split,
+                   "streams": S,
                    "weights": "seeded synthetic (yolo_amd.synthetic.init_deterministic)"},
         "roofline": {"bound": "mfma", "kernel": dom_label, "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(dom_tf / peak, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -17,7 +17,8 @@ def init_from_env(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if device_type == "cuda":
+        # YDET_DIST_BACKEND=gloo: rehearse the multi-process control flow on a box with fewer GPUs than ranks
+        if device_type == "cuda" and os.environ.get("YDET_DIST_BACKEND", "nccl") == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:

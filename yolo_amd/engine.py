@@ -682,6 +682,10 @@ class PlanCache:
         if sig != self.signature:
             self.plans.clear()
             self.signature = sig
+        # a plan owns its activation arena: forward passes issued on different streams may overlap on the GPU and must
+        # not share one, so the stream is part of the key (callers that pipeline batches over two streams get two plans)
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            key = (key, torch.cuda.current_stream().cuda_stream)
         p = self.plans.get(key)
         if p is None:
             p = self.plans[key] = build()
