@@ -376,3 +376,26 @@ def test_errors_are_loud():
     from yolo_amd.yolov5_official.utils import non_max_suppression
     with pytest.raises(RuntimeError):
         non_max_suppression(torch.zeros(1, 10, 85))
+
+
+def test_two_streams_have_their_own_plans():
+    """Forward passes issued on two streams overlap on the GPU: each stream gets a plan (activation arena) of its own
+    and the results equal the single-stream ones bit for bit."""
+    engine.set_compute_dtype("bf16")
+    m = build_v5s(80).to(DEV)
+    xa, xb = images(4, 128, seed=21).to(DEV), images(4, 128, seed=22).to(DEV)
+    with torch.no_grad():
+        ref_a, ref_b = m(xa)[0].clone(), m(xb)[0].clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+        outs = []
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                za = m(xa)[0]
+            with torch.cuda.stream(s2):
+                zb = m(xb)[0]
+            outs.append((za, zb))
+        torch.cuda.synchronize()
+    assert len(m._plans().plans) == 3          # default stream + the two side streams
+    for za, zb in outs:
+        assert torch.equal(za, ref_a) and torch.equal(zb, ref_b)
