@@ -257,6 +257,15 @@ int ydet_nms_perclass(const float* boxes, const float* scores, int N, int n, int
 /* box_iou: yolov5_official/utils.py:601-611.  a [na,4], b [nb,4] xyxy fp32 -> iou [na, nb]. */
 int ydet_box_iou(const float* a, int na, const float* b, int nb, float* iou, void* stream);
 
+/* process_batch: yolov5_official/utils.py:1103-1123 (the TP matrix of yolov5_official/val.py:27-186), for a batch of
+ * images in one launch.  det [B, max_det, 6] (xyxy, conf, cls; rows >= count[b] ignored) and count [B] as written by
+ * ydet_nms_v5 (boxes already in the labels' coordinate space); labels [L, 5] (cls, xyxy) grouped by image,
+ * label_start [B + 1] their offsets; iouv [niou] ascending thresholds.  correct [B, max_det, niou] uint8: row j is
+ * `best_iou > iouv` when prediction j is the first of its class to reach IoU > iouv[0] with its best same-class
+ * label, else zeros.  All pointers are device pointers.  max_det <= 4096. */
+int ydet_process_batch(const float* det, const int32_t* count, int B, int max_det, const float* labels,
+                       const int32_t* label_start, const float* iouv, int niou, uint8_t* correct, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Launch-list executor: one call runs a whole pre-planned forward pass
  * (the Python loop of Model.forward_once, yolov5_official/model.py:220-234, and the forward()

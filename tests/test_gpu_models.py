@@ -399,3 +399,51 @@ def test_two_streams_have_their_own_plans():
     assert len(m._plans().plans) == 3          # default stream + the two side streams
     for za, zb in outs:
         assert torch.equal(za, ref_a) and torch.equal(zb, ref_b)
+
+
+def test_val_run_device_tail_matches_host_recomputation():
+    """yolov5_official/val.py:27-186 end to end on synthetic data: val.run (TP matching of all images in one launch on
+    the device) against the same metrics recomputed on the host with the oracle's process_batch."""
+    from oracle import metrics as OM
+    from yolo_amd.yolov5_official import utils as U, val as V
+    engine.set_compute_dtype("fp32")
+    nc = 20
+    m = build_v5s(nc).to(DEV).eval()
+    gen = torch.Generator().manual_seed(5)
+    batches = []
+    with torch.no_grad():
+        for b in range(3):
+            img = (torch.rand(2, 3, 64, 64, generator=gen) * 255).to(torch.uint8)
+            out, _ = m(img.to(DEV).float() / 255.0)
+            dets = U.non_max_suppression(out, 0.001, 0.6, multi_label=True)
+            tg = []
+            for si, d in enumerate(dets):           # labels: some of the image's own detections, jittered
+                k = min(len(d), 5)
+                if b == 2 and si == 1:
+                    k = 0                            # an image without labels
+                box = d[:k, :4].cpu() + torch.randn(k, 4, generator=gen) * 1.5
+                xywh = U.xyxy2xywh(box) / 64.0
+                tg.append(torch.cat([torch.full((k, 1), float(si)), d[:k, 5:6].cpu(), xywh], 1))
+            shapes = [((64, 64), ((1.0, 1.0), (0.0, 0.0)))] * 2
+            batches.append((img, torch.cat(tg, 0), [f"im{b}_{i}.jpg" for i in range(2)], shapes))
+    res, maps, _ = V.run({"nc": nc}, model=m, dataloader=batches, device="cuda", half=False)
+    mp, mr, map50, map95 = res[:4]
+    # host recomputation
+    iouv = np.linspace(0.5, 0.95, 10).astype(np.float32)
+    stats = []
+    with torch.no_grad():
+        for img, targets, _, _ in batches:
+            out, _ = m(img.to(DEV).float() / 255.0)
+            dets = U.non_max_suppression(out, 0.001, 0.6, multi_label=True)
+            t = targets.clone()
+            t[:, 2:] *= 64.0
+            for si, d in enumerate(dets):
+                lab = t[t[:, 0] == si, 1:]
+                lab = torch.cat([lab[:, :1], U.xywh2xyxy(lab[:, 1:5])], 1).numpy()
+                d = d.cpu().numpy()
+                correct = OM.process_batch(d, lab, iouv) if len(lab) and len(d) else np.zeros((len(d), 10), bool)
+                stats.append((correct, d[:, 4], d[:, 5], lab[:, 0].tolist()))
+    stats = [np.concatenate(x, 0) for x in zip(*stats)]
+    p, r, ap, f1, _ = U.ap_per_class(*stats)
+    assert stats[0].any() and 0.0 < map50 <= 1.0
+    np.testing.assert_allclose([mp, mr, map50, map95], [p.mean(), r.mean(), ap[:, 0].mean(), ap.mean()], rtol=1e-6)

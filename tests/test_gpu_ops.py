@@ -487,3 +487,50 @@ def test_conv_second_destination(c0, c1, cin, k):
     ref = _run_graph(joint, x, compute="bf16")["y"].float().cpu()
     out = _run_graph(separate, x, compute="bf16")
     assert torch.equal(out["a"].float().cpu(), ref[:, :c0]) and torch.equal(out["b"].float().cpu(), ref[:, c0:])
+
+
+# ---- evaluation tail on the device -----------------------------------------------------------------------------------
+def test_process_batch_golden_and_batched(golden):
+    """ydet_process_batch against the reference's own output (fixture G7) and, batched with ragged counts, against the
+    oracle: images without labels, without predictions, classes without labels, duplicate predictions that compete for
+    one label, a degenerate (NaN IoU) pair."""
+    from oracle import metrics as OM
+    from yolo_amd.yolov5_official import utils as U
+    g = golden("g7_v5_metrics")
+    iouv = torch.from_numpy(g["iouv"]).to(DEV)
+    got = U.process_batch(torch.from_numpy(g["preds"]).to(DEV), torch.from_numpy(g["labels"]).to(DEV), iouv)
+    assert got.is_cuda and got.dtype == torch.bool
+    np.testing.assert_array_equal(got.cpu().numpy(), g["correct"])
+
+    gen = _gen(13, "pb")
+    B, max_det = 6, 40
+    det = torch.zeros(B, max_det, 6)
+    counts = [40, 0, 17, 25, 40, 3]
+    labels, starts = [], [0]
+    for b in range(B):
+        nl = [9, 4, 0, 6, 12, 2][b]
+        xy = torch.rand(nl, 2, generator=gen) * 300
+        lb = torch.cat([torch.randint(0, 3, (nl, 1), generator=gen).float(), xy, xy + torch.rand(nl, 2, generator=gen) * 80 + 5], 1)
+        labels.append(lb)
+        starts.append(starts[-1] + nl)
+        n = counts[b]
+        if n and nl:
+            src = lb[torch.randint(0, nl, (n,), generator=gen)]
+            det[b, :n, :4] = src[:, 1:] + torch.randn(n, 4, generator=gen) * 6
+            det[b, :n, 5] = torch.where(torch.rand(n, generator=gen) < 0.8, src[:, 0], torch.full((n,), 4.0))
+        elif n:
+            det[b, :n, :4] = torch.rand(n, 4, generator=gen) * 300
+        det[b, :n, 4] = torch.rand(n, generator=gen)
+    det[0, 1] = det[0, 0]                       # an exact duplicate: only the first may claim
+    labels[4][0, 1:] = torch.tensor([10., 10., 10., 10.])       # zero-area label and prediction of its class: 0 / 0
+    det[4, 0, :4] = torch.tensor([50., 50., 50., 50.])
+    det[4, 0, 5] = labels[4][0, 0]
+    lab = torch.cat(labels, 0)
+    got = ops.process_batch(det.to(DEV), torch.tensor(counts, dtype=torch.int32, device=DEV), lab.to(DEV),
+                            torch.tensor(starts, dtype=torch.int32, device=DEV), iouv).cpu().numpy()
+    for b in range(B):
+        n = counts[b]
+        ref = OM.process_batch(det[b, :n].numpy(), labels[b].numpy(), g["iouv"]) if n and len(labels[b]) else np.zeros((n, 10), bool)
+        np.testing.assert_array_equal(got[b, :n], ref, err_msg=f"image {b}")
+        assert not got[b, n:].any()
+    assert got[0, 0].any() and not got[0, 1].any()

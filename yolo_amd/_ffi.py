@@ -89,6 +89,8 @@ SYMBOLS = {
     "ydet_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "ydet_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "ydet_head_conv_decode": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(HeadDesc), C.c_void_p]),
+    "ydet_process_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
     "ydet_bottleneck_fused": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
     "ydet_decode_v5": (C.c_int, [C.POINTER(V5Level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),

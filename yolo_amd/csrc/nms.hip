@@ -708,6 +708,64 @@ __global__ void box_iou_kernel(const float4* a, int na, const float4* b, int nb,
     out[gid] = inter / (a1 + a2 - inter);
 }
 
+
+// process_batch (yolov5_official/utils.py:1103-1123) for a batch of images, one workgroup per image.  Per prediction:
+// the label of its own class with the largest IoU (first one on ties, NaN if any IoU is NaN -- both as torch.max);
+// a prediction whose best IoU exceeds iouv[0] claims that label unless an earlier prediction of the class already
+// did (the reference walks predictions in index order), and only a claiming prediction gets its row best > iouv.
+// The reference's early exit once every label is claimed changes nothing: no later prediction can claim by then.
+__global__ __launch_bounds__(256) void process_batch_kernel(const float* det, const int32_t* count, int max_det,
+                                                             const float* labels, const int32_t* label_start,
+                                                             const float* iouv, int niou, uint8_t* correct) {
+    __shared__ float s_best[kMaxNms];
+    __shared__ int s_lab[kMaxNms];
+    __shared__ float s_cls[kMaxNms];
+    const int img = blockIdx.x;
+    const int n = min(count[img], max_det);
+    const int l0 = label_start[img], l1 = label_start[img + 1];
+    const float* d = det + (size_t)img * max_det * 6;
+    uint8_t* out = correct + (size_t)img * max_det * niou;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float4 p = make_float4(d[j * 6 + 0], d[j * 6 + 1], d[j * 6 + 2], d[j * 6 + 3]);
+        const float pc = d[j * 6 + 5];
+        const float a1 = (p.z - p.x) * (p.w - p.y);
+        float best = -INFINITY;
+        int lab = -1;
+        bool nan = false;
+        for (int l = l0; l < l1; ++l) {
+            const float* q = labels + (size_t)l * 5;
+            if (q[0] != pc) continue;
+            const float a2 = (q[3] - q[1]) * (q[4] - q[2]);
+            const float w = fmaxf(fminf(p.z, q[3]) - fmaxf(p.x, q[1]), 0.f);
+            const float h = fmaxf(fminf(p.w, q[4]) - fmaxf(p.y, q[2]), 0.f);
+            const float inter = w * h;
+            const float iou = inter / (a1 + a2 - inter);
+            if (iou != iou) nan = true;
+            if (iou > best) { best = iou; lab = l; }
+        }
+        s_best[j] = nan ? NAN : best;
+        s_lab[j] = lab;
+        s_cls[j] = pc;
+    }
+    __syncthreads();
+    const float thr0 = iouv[0];
+    for (int j = threadIdx.x; j < max_det; j += 256) {
+        bool claims = false;
+        float best = 0.f;
+        if (j < n) {
+            best = s_best[j];
+            const int lab = s_lab[j];
+            claims = lab >= 0 && best > thr0;
+            if (claims) {
+                const float pc = s_cls[j];
+                for (int k = 0; k < j; ++k)
+                    if (s_lab[k] == lab && s_cls[k] == pc && s_best[k] > thr0) { claims = false; break; }
+            }
+        }
+        for (int t = 0; t < niou; ++t) out[(size_t)j * niou + t] = claims && best > iouv[t] ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t ydet_nms_v5_workspace_bytes(int N, int nboxes, int no) {
@@ -812,5 +870,19 @@ extern "C" int ydet_box_iou(const float* a, int na, const float* b, int nb, floa
     hipLaunchKernelGGL(box_iou_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        (const float4*)a, na, (const float4*)b, nb, iou);
     YDET_CHECK_LAUNCH("box_iou_kernel");
+    return YDET_OK;
+}
+
+extern "C" int ydet_process_batch(const float* det, const int32_t* count, int B, int max_det, const float* labels,
+                                  const int32_t* label_start, const float* iouv, int niou, uint8_t* correct,
+                                  void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(B >= 0 && max_det >= 1 && max_det <= kMaxNms && niou >= 1, "process_batch: B=%d max_det=%d niou=%d (max_det <= %d)",
+                   B, max_det, niou, kMaxNms);
+    if (B == 0) return YDET_OK;
+    YDET_CHECK_ARG(det && count && label_start && iouv && correct, "process_batch: null pointer");
+    hipLaunchKernelGGL(process_batch_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), det, count, max_det, labels,
+                       label_start, iouv, niou, correct);
+    YDET_CHECK_LAUNCH("process_batch_kernel");
     return YDET_OK;
 }

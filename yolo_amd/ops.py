@@ -166,3 +166,26 @@ def box_iou(box1, box2):
         _ffi.check(lib.ydet_box_iou(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(),
                                     _ffi.current_stream()), "ydet_box_iou")
     return out
+
+
+def process_batch(det, count, labels, label_start, iouv):
+    """TP matrices of a batch in one launch (yolov5_official/utils.py:1103-1123 per image).
+    det [B, max_det, 6] fp32, count [B] int32, labels [L, 5] (cls, xyxy) grouped by image, label_start [B + 1] int32,
+    iouv [k] fp32, all CUDA.  Returns correct [B, max_det, k] bool (rows >= count are False)."""
+    _need_cuda(det, count, label_start, iouv)
+    lib = _ffi.lib()
+    det = det.float().contiguous()
+    count = count.to(torch.int32).contiguous()
+    labels = labels.float().contiguous()
+    label_start = label_start.to(torch.int32).contiguous()
+    iouv = iouv.float().contiguous()
+    B, max_det, _ = det.shape
+    out = torch.empty(B, max_det, iouv.numel(), device=det.device, dtype=torch.uint8)
+    if B == 0:
+        return out.bool()
+    assert label_start.numel() == B + 1 and count.numel() == B
+    with torch.cuda.device(det.device):
+        _ffi.check(lib.ydet_process_batch(det.data_ptr(), count.data_ptr(), B, max_det, labels.data_ptr(),
+                                          label_start.data_ptr(), iouv.data_ptr(), iouv.numel(), out.data_ptr(),
+                                          _ffi.current_stream()), "ydet_process_batch")
+    return out.bool()

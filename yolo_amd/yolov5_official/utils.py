@@ -116,8 +116,12 @@ def process_batch(predictions, labels, iouv):
     """TP matrix [n_pred, n_iou] of one image: per class, predictions whose best IoU with a label of that
     class exceeds iouv[0] claim that label once, in prediction order."""
     n = predictions.shape[0]
-    correct = np.zeros((n, len(iouv)), dtype=bool)
     nl = labels.shape[0]
+    if predictions.is_cuda and n and nl:      # one launch on the device (ydet_process_batch), nothing leaves the GPU
+        dev = predictions.device
+        return ops.process_batch(predictions[None, :, :6], torch.tensor([n], device=dev, dtype=torch.int32), labels.to(dev),
+                                 torch.tensor([0, nl], device=dev, dtype=torch.int32), iouv.to(dev))[0]
+    correct = np.zeros((n, len(iouv)), dtype=bool)
     if n and nl:
         iou_all = box_iou(predictions[:, :4], labels[:, 1:5]).cpu().numpy()
         pcls = predictions[:, 5].cpu().numpy()

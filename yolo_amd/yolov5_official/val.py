@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .. import distributed as ydist
+from .. import ops
 from .utils import (ap_per_class, non_max_suppression_padded, process_batch, scale_coords, xywh2xyxy, xyxy2xywh)
 
 
@@ -120,17 +121,36 @@ def run(data,
     cnt_host = cnt.tolist()
     iid_host = iid.tolist()
     tgt_img = tgt[:, 0].long() if len(tgt) else tgt.new_zeros(0, dtype=torch.long)
-    for k, image in enumerate(iid_host):
-        pred = det[k, :cnt_host[k]]
-        labels = tgt[tgt_img == image, 1:]
-        nl = len(labels)
-        tcls = labels[:, 0].tolist() if nl else []
-        if len(pred) == 0:
-            if nl:
-                stats.append((torch.zeros(0, niou, dtype=torch.bool), torch.Tensor(), torch.Tensor(), tcls))
-            continue
-        correct = process_batch(pred, labels, iouv) if nl else torch.zeros(pred.shape[0], niou, dtype=torch.bool)
-        stats.append((correct.cpu(), pred[:, 4].cpu(), pred[:, 5].cpu(), tcls))
+    if dev.type == "cuda" and seen:
+        # the TP matrices of every image in one launch; only booleans, confidences and classes leave the GPU
+        pos = torch.searchsorted(iid, tgt_img)                       # row of each label's image (iid is sorted)
+        order = torch.argsort(pos, stable=True)
+        per_img = torch.bincount(pos, minlength=seen)
+        start = torch.zeros(seen + 1, device=dev, dtype=torch.int32)
+        start[1:] = torch.cumsum(per_img, 0)
+        lab_sorted = tgt[order, 1:]
+        correct_all = ops.process_batch(det, cnt, lab_sorted, start, iouv).cpu()
+        conf_all, cls_all = det[..., 4].cpu(), det[..., 5].cpu()
+        start_host, tcls_host = start.tolist(), lab_sorted[:, 0].tolist()
+        for k in range(seen):
+            c, tcls = cnt_host[k], tcls_host[start_host[k]:start_host[k + 1]]
+            if c == 0:
+                if tcls:
+                    stats.append((torch.zeros(0, niou, dtype=torch.bool), torch.Tensor(), torch.Tensor(), tcls))
+                continue
+            stats.append((correct_all[k, :c], conf_all[k, :c], cls_all[k, :c], tcls))
+    else:
+        for k, image in enumerate(iid_host):
+            pred = det[k, :cnt_host[k]]
+            labels = tgt[tgt_img == image, 1:]
+            nl = len(labels)
+            tcls = labels[:, 0].tolist() if nl else []
+            if len(pred) == 0:
+                if nl:
+                    stats.append((torch.zeros(0, niou, dtype=torch.bool), torch.Tensor(), torch.Tensor(), tcls))
+                continue
+            correct = process_batch(pred, labels, iouv) if nl else torch.zeros(pred.shape[0], niou, dtype=torch.bool)
+            stats.append((correct.cpu(), pred[:, 4].cpu(), pred[:, 5].cpu(), tcls))
 
     p = r = f1 = mp = mr = map50 = map95 = 0.0
     ap, ap_class = [], []
