@@ -177,6 +177,60 @@ def v2d19_heads(sd, x):                                                         
     return [_pred(conv_a(torch.cat([r, p6], 1), sd, "convsets2"), sd, "pred")]
 
 
+def _reorg2(r):                                                                       # moduleUtils.py:33-41
+    b, c, h, w = r.shape
+    r = r.view(b, c, h // 2, 2, w // 2, 2).transpose(3, 4).contiguous()
+    r = r.view(b, c, (h // 2) * (w // 2), 4).transpose(2, 3).contiguous()
+    return r.view(b, c, 4, (h // 2) * (w // 2)).transpose(1, 2).contiguous().view(b, -1, h // 2, w // 2)
+
+
+def _cbr(x, sd, conv, bn, s=1, relu=True):
+    """Conv2d(no bias) + BN(eps 1e-5) [+ ReLU] as the ResNet trunk composes them (basemodel/resnet.py:13-20)."""
+    w = sd[conv + ".weight"]
+    y = _bn(F.conv2d(x, w, None, stride=s, padding=w.shape[-1] // 2), sd, bn, 1e-5)
+    return F.relu(y) if relu else y
+
+
+def _basic_block(x, sd, p, s):                                                        # basemodel/resnet.py:24-54
+    out = _cbr(_cbr(x, sd, p + ".conv1", p + ".bn1", s=s), sd, p + ".conv2", p + ".bn2", relu=False)
+    if p + ".downsample.0.weight" in sd:
+        x = _cbr(x, sd, p + ".downsample.0", p + ".downsample.1", s=s, relu=False)
+    return F.relu(out + x)
+
+
+def resnet18_trunk(sd, x, p="base"):                                                  # basemodel/resnet.py:96-155
+    """ResNet([2,2,2,2]) as models/v2r50.py:39 builds it; forward() skips self.maxpool (:148-155)."""
+    y = _cbr(x, sd, p + ".first_layer.0", p + ".first_layer.1", s=2)
+    outs = []
+    for li, s in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        for b in range(2):
+            y = _basic_block(y, sd, f"{p}.layer{li}.{b}", s if b == 0 else 1)
+        outs.append(y)
+    return outs[1], outs[2], outs[3]
+
+
+def v2r50_heads(sd, x):                                                               # models/v2r50.py:68-82
+    _, c5, c6 = resnet18_trunk(sd, x)
+    p6 = conv_a(conv_a(conv_a(c6, sd, "convset1.0"), sd, "convset1.1"), sd, "convset1.2")
+    p5 = _reorg2(conv_a(c5, sd, "route_layer"))
+    return [_pred(conv_a(torch.cat([p5, p6], 1), sd, "convset2"), sd, "pred")]
+
+
+def darknet_tiny(sd, x, p="base"):                                                    # d19.py:127-166
+    outs = []
+    for i in range(1, 6):
+        x = conv_a(conv_a(x, sd, f"{p}.conv_{i}.0"), sd, f"{p}.conv_{i}.1", s=2)
+        outs.append(x)
+    return outs[2], outs[3], outs[4]
+
+
+def v2slim_heads(sd, x):                                                              # models/v2slim.py:48-60
+    _, c5, c6 = darknet_tiny(sd, x)
+    p6 = conv_a(conv_a(c6, sd, "convset1.0"), sd, "convset1.1")
+    p5 = _reorg2(conv_a(c5, sd, "route_layer"))
+    return [_pred(conv_a(torch.cat([p5, p6], 1), sd, "convset2"), sd, "pred")]
+
+
 def _set5(x, sd, p, first=0):
     for i in range(first, first + 5):
         x = conv_a(x, sd, f"{p}.{i}")

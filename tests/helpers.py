@@ -10,16 +10,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from yolo_amd.models import model_config as mc  # noqa: E402
-from yolo_amd.synthetic import images, init_deterministic  # noqa: E402
+from yolo_amd.synthetic import V2R50_HEAD_SCALE, images, init_deterministic  # noqa: E402
 
 FA_SPECS = {
     # tag: (module, class, config dict, head conv attribute names fine->coarse, decode is "v2", oracle net)
     "v3tiny": ("yolo_amd.models.v3tiny", "YOLOv3", mc.yolov3_tiny_cfg, ["pred_1", "pred_2"], False, "v3tiny_heads"),
     "v2d19": ("yolo_amd.models.v2d19", "YOLOv2", mc.yolov2_d19_cfg, ["pred"], True, "v2d19_heads"),
+    "v2r50": ("yolo_amd.models.v2r50", "YOLOv2", mc.yolov2_r50_cfg, ["pred"], True, "v2r50_heads"),
+    "v2slim": ("yolo_amd.models.v2slim", "YOLOv2", mc.yolov2_slim_cfg, ["pred"], True, "v2slim_heads"),
     "v3spp": ("yolo_amd.models.v3spp", "YOLOv3", mc.yolov3_d53_cfg, ["pred_1", "pred_2", "pred_3"], True, "v3spp"),
     "v3": ("yolo_amd.models.v3", "YOLOv3", mc.yolov3_d53_cfg, ["pred_1", "pred_2", "pred_3"], False, "v3"),
     "v4": ("yolo_amd.models.v4", "YOLOv4", mc.yolov4_cfg, ["head_det_1", "head_det_2", "head_det_3"], True, "v4_heads"),
 }
+
+
+def fa_thresholds(tag):
+    """(conf_thresh, nms_thresh) defaults of the detector's constructor (what the recorded runs used)."""
+    return {"v2r50": (0.001, 0.6), "v2slim": (0.01, 0.5)}.get(tag, (0.001, 0.5))
 
 
 def build_fa(tag, size, seed=0):
@@ -27,6 +34,8 @@ def build_fa(tag, size, seed=0):
     modname, cls, cfg, heads, v2, _ = FA_SPECS[tag]
     net = getattr(importlib.import_module(modname), cls)(size, 20, False, anchor_size=cfg["anchor_size_voc"])
     init_deterministic(net, seed=seed)
+    if tag == "v2r50":
+        net.pred.weight.data *= V2R50_HEAD_SCALE
     return net.eval()
 
 

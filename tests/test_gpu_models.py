@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FA_SPECS, build_fa, build_v5s, oracle_fa_heads, rel_err, v5s_cfg
+from helpers import FA_SPECS, build_fa, build_v5s, fa_thresholds, oracle_fa_heads, rel_err, v5s_cfg
 from oracle import nets as ON
 from oracle import postproc as O
 from yolo_amd import _ffi, engine
@@ -282,7 +282,8 @@ def test_v5s_end_to_end_nms_vs_oracle():
 
 
 # ---- v2 / v3 / v4 detectors -----------------------------------------------------------------------------------------
-FA_CASES = [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v2d19", 416), ("v3spp", 128), ("v3", 128), ("v4", 128)]
+FA_CASES = [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v2d19", 416), ("v3spp", 128), ("v3", 128), ("v4", 128),
+            ("v2r50", 128), ("v2r50", 416), ("v2slim", 128), ("v2slim", 416)]
 
 
 @pytest.mark.parametrize("compute", ["fp32", "bf16"])
@@ -299,8 +300,7 @@ def test_family_a_heads_golden(golden, compute, tag, size):
         assert rel_err(h.cpu().numpy(), g["head_" + name]) < tol, name
 
 
-@pytest.mark.parametrize("tag,size", [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v2d19", 416), ("v3spp", 128),
-                                      ("v3", 128), ("v4", 128)])
+@pytest.mark.parametrize("tag,size", FA_CASES)
 def test_family_a_detections(golden, tag, size):
     """forward() contract: numpy (bboxes [K,4] f32, scores [K] f32, cls [K] i64) of image 0 in box-index order.
     With random weights the class softmax is nearly flat, so the argmax class (hence the per-class NMS
@@ -328,7 +328,8 @@ def test_family_a_detections(golden, tag, size):
         np.testing.assert_array_equal(cl, rc)
 
 
-@pytest.mark.parametrize("tag,size", [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v3spp", 128), ("v3", 128), ("v4", 128)])
+@pytest.mark.parametrize("tag,size", [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v3spp", 128), ("v3", 128), ("v4", 128),
+                                      ("v2r50", 128), ("v2r50", 416), ("v2slim", 128), ("v2slim", 416)])
 def test_family_a_nms_on_recorded_boxes(golden, tag, size):
     """The reference's own (bboxes, scores) -> its own kept detections, through ydet_nms_perclass: exact."""
     from yolo_amd import ops
@@ -337,7 +338,7 @@ def test_family_a_nms_on_recorded_boxes(golden, tag, size):
     if len(np.unique(best)) != len(best):
         pytest.skip("recorded scores contain exact ties: the reference's visiting order is implementation-defined")
     keep, cls, sc = ops.nms_perclass(torch.from_numpy(g["pre_bboxes"]).to(DEV)[None],
-                                     torch.from_numpy(g["pre_scores"]).to(DEV)[None], 0.001, 0.5)
+                                     torch.from_numpy(g["pre_scores"]).to(DEV)[None], *fa_thresholds(tag))
     k = keep[0].bool().cpu().numpy()
     np.testing.assert_array_equal(g["pre_bboxes"][k], g["out_bboxes"])
     np.testing.assert_array_equal(sc[0].cpu().numpy()[k], g["out_scores"])

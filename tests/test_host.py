@@ -71,7 +71,8 @@ def test_state_dict_structure_matches_reference():
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "g8_structure.json")))
     keys = lambda m: [[k, list(v.shape)] for k, v in m.state_dict().items()]
     assert keys(build_v5s(80)) == ref["yolov5s_nc80"]
-    for tag, size in (("v3tiny", 416), ("v2d19", 416), ("v3spp", 608), ("v3", 416), ("v4", 608)):
+    for tag, size in (("v3tiny", 416), ("v2d19", 416), ("v2r50", 416), ("v2slim", 416), ("v3spp", 608), ("v3", 416),
+                      ("v4", 608)):
         assert keys(build_fa(tag, size)) == ref[tag], tag
 
 
@@ -158,7 +159,8 @@ def test_planner_v5s_on_cpu():
     assert set(g.outputs) == {"z", "row_max", "head0", "head1", "head2"}
 
 
-@pytest.mark.parametrize("tag,size,convs", [("v3tiny", 416, 13), ("v2d19", 416, 23), ("v3spp", 608, 75), ("v4", 608, 120)])
+@pytest.mark.parametrize("tag,size,convs", [("v3tiny", 416, 13), ("v2d19", 416, 23), ("v3spp", 608, 75), ("v4", 608, 120),
+                                          ("v2r50", 416, 26), ("v2slim", 416, 15)])
 def test_planner_family_a_on_cpu(tag, size, convs):
     from yolo_amd import engine
     from yolo_amd.models._anchor_detector import _HeadLowerOps

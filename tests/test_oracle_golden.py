@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FA_SPECS, build_fa, build_v5s, oracle_fa_heads, rel_err, v5s_cfg
+from helpers import FA_SPECS, build_fa, build_v5s, fa_thresholds, oracle_fa_heads, rel_err, v5s_cfg
 from oracle import metrics as OM
 from oracle import nets as ON
 from oracle import postproc as O
@@ -32,7 +32,8 @@ def test_transposed_grid_differs(golden):
 
 
 # ---- G2 / G6: family-A decode from recorded head maps, and oracle networks ---------------------------
-FA_CASES = [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v2d19", 416), ("v3spp", 128), ("v3", 128), ("v4", 128)]
+FA_CASES = [("v3tiny", 64), ("v3tiny", 416), ("v2d19", 128), ("v2d19", 416), ("v3spp", 128), ("v3", 128), ("v4", 128),
+            ("v2r50", 128), ("v2r50", 416), ("v2slim", 128), ("v2slim", 416)]
 
 
 @pytest.mark.parametrize("tag,size", FA_CASES)
@@ -64,11 +65,13 @@ def assert_same_detections(bb, sc, cl, g, scores_in):
 @pytest.mark.parametrize("tag,size", FA_CASES)
 def test_family_a_postprocess_on_recorded_boxes(golden, tag, size):
     g = golden(f"g6_{tag}_{size}")
-    bb, sc, cl = O.postprocess(g["pre_bboxes"], g["pre_scores"], 0.001, 20, 0.5)
+    conf, thr = fa_thresholds(tag)
+    bb, sc, cl = O.postprocess(g["pre_bboxes"], g["pre_scores"], conf, 20, thr)
     assert_same_detections(bb, sc, cl, g, g["pre_scores"])
 
 
-@pytest.mark.parametrize("tag,size", [("v3tiny", 64), ("v2d19", 128), ("v3spp", 128), ("v3", 128), ("v4", 128)])
+@pytest.mark.parametrize("tag,size", [("v3tiny", 64), ("v2d19", 128), ("v3spp", 128), ("v3", 128), ("v4", 128),
+                                      ("v2r50", 128), ("v2slim", 128)])
 def test_oracle_networks(golden, tag, size):
     g = golden(f"g6_{tag}_{size}")
     net = build_fa(tag, size)

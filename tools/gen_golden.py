@@ -44,8 +44,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default="", help="write only the fixtures whose name starts with this prefix")
+    ap.add_argument("--only", default="", help="write only the fixtures whose name starts with one of these comma-separated prefixes")
     args = ap.parse_args()
+    args.only = tuple(args.only.split(","))
     os.makedirs(args.out, exist_ok=True)
     import_reference(args.ref)
 
@@ -53,7 +54,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     from oracle import postproc as O
-    from yolo_amd.synthetic import _gen, clustered_predictions, images, init_deterministic
+    from yolo_amd.synthetic import V2R50_HEAD_SCALE, _gen, clustered_predictions, images, init_deterministic
 
     def save(name, **arrs):
         if not name.startswith(args.only):
@@ -121,6 +122,10 @@ def main():
         cls = getattr(sys.modules[modname], cls_name)
         net = cls(size, 20, False, anchor_size=cfg["anchor_size_voc"])
         init_deterministic(net, seed=0)
+        if modname == "models.v2r50":
+            # the residual trunk lets activations grow with random BatchNorm gains: without this the 416 head map
+            # reaches +-50 and most scores saturate to exactly 1.0 (ties whose visiting order numpy leaves open)
+            net.pred.weight.data *= V2R50_HEAD_SCALE
         return net
 
     def sample(a, step=53):
@@ -139,6 +144,14 @@ def main():
         x = images(1, size, seed=size + 1, kind="randn")
         r = run_family_a("v2d19", net, x, ["pred"])
         save(f"g6_v2d19_{size}", x_seed=size + 1, **r)
+    # v2r50 (ResNet([2,2,2,2]) trunk, head at stride 16) and v2slim (DarkNet_Tiny trunk, stride 32)
+    import models.v2r50, models.v2slim
+    for tag, cfg, sizes in (("v2r50", rcfg.yolov2_r50_cfg, (128, 416)), ("v2slim", rcfg.yolov2_slim_cfg, (128, 416))):
+        for size in sizes:
+            net = fa_model(f"models.{tag}", "YOLOv2", size, cfg)
+            x = images(1, size, seed=size + 2, kind="randn")
+            r = run_family_a(tag, net, x, ["pred"])
+            save(f"g6_{tag}_{size}", x_seed=size + 2, **r)
     # v3spp / v3: small full tensors at 128 (v3spp also at 608: sampled, final outputs full)
     for modname, tag in (("models.v3spp", "v3spp"), ("models.v3", "v3")):
         net = fa_model(modname, "YOLOv3", 128, rcfg.yolov3_d53_cfg)
@@ -404,6 +417,8 @@ def main():
     struct["yolov5s_nc80_extra"] = {"save": list(rmodel.Model(cfg_path).save), "stride": [8.0, 16.0, 32.0]}
     struct["v3tiny"] = keys_of(fa_model("models.v3tiny", "YOLOv3", 416, rcfg.yolov3_tiny_cfg))
     struct["v2d19"] = keys_of(fa_model("models.v2d19", "YOLOv2", 416, rcfg.yolov2_d19_cfg))
+    struct["v2r50"] = keys_of(fa_model("models.v2r50", "YOLOv2", 416, rcfg.yolov2_r50_cfg))
+    struct["v2slim"] = keys_of(fa_model("models.v2slim", "YOLOv2", 416, rcfg.yolov2_slim_cfg))
     struct["v3spp"] = keys_of(fa_model("models.v3spp", "YOLOv3", 608, rcfg.yolov3_d53_cfg))
     struct["v3"] = keys_of(fa_model("models.v3", "YOLOv3", 416, rcfg.yolov3_d53_cfg))
     struct["v4"] = keys_of(fa_model("models.v4", "YOLOv4", 608, rcfg.yolov4_cfg))

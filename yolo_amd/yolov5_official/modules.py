@@ -30,6 +30,8 @@ def activation_code(act):
         return _ffi.ACT_SILU, 0.0
     if isinstance(act, nn.LeakyReLU):
         return _ffi.ACT_LEAKY, float(act.negative_slope)
+    if isinstance(act, nn.ReLU):          # the leaky form with slope 0
+        return _ffi.ACT_LEAKY, 0.0
     if type(act).__name__ == "SiLU":  # hand-written x*sigmoid(x) modules
         return _ffi.ACT_SILU, 0.0
     raise NotImplementedError(f"activation {type(act).__name__} has no fused epilogue")
