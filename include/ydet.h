@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 6
+#define YDET_ABI_VERSION 7
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -265,6 +265,38 @@ int ydet_box_iou(const float* a, int na, const float* b, int nb, float* iou, voi
  * label, else zeros.  All pointers are device pointers.  max_det <= 4096. */
 int ydet_process_batch(const float* det, const int32_t* count, int B, int max_det, const float* labels,
                        const int32_t* label_start, const float* iouv, int niou, uint8_t* correct, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Image pre-processing: a batch of uint8 HWC images (3 interleaved channels, any sizes) -> the network input.
+ * Replaces the host chain  letterbox (yolov5_official/utils.py:40-75: cv2.resize INTER_LINEAR + cv2.copyMakeBorder
+ * with 114) -> img[:, :, ::-1].transpose(2, 0, 1) -> img / 255 (yolov5_official/val.py:68-69), and
+ * base_transform (data/transformers.py:456-471: cv2.resize -> /255 -> -mean -> /std) -> img[:, :, (2, 1, 0)] ->
+ * permute(2, 0, 1) (data/dataset.py:224-229).
+ *
+ * Per image: the source is resampled to rw x rh (== w x h: copied; exactly half in both directions: 2x2 box mean;
+ * otherwise OpenCV's 8-bit bilinear arithmetic, see csrc/preproc.hip) and placed with its top-left corner at
+ * (left, top) of the out_w x out_h canvas; canvas pixels outside it take pad_value.  The geometry (rw, rh, left,
+ * top) is the caller's: letterbox and base_transform differ only there.  Then per channel, in the source's channel
+ * order c:  scale_mode 0: v;  1: v / 255;  2: (v / 255 - mean[c]) / std[c]  (IEEE fp32, in this order).  Output
+ * channel k shows source channel (swap_rb ? 2 - k : k).  out: [N, 3, out_h, out_w] (layout 0) or
+ * [N, out_h, out_w, 3] (layout 1) of out_dtype (YDET_U8 only with scale_mode 0).
+ * ------------------------------------------------------------------------------------------ */
+#define YDET_U8 2 /* output dtype of ydet_preprocess_u8 only */
+typedef struct {
+    const uint8_t* data;  /* device pointer; pixel (y, x) channel c at data[y*pitch + 3*x + c] */
+    int32_t h, w, pitch;
+    int32_t rh, rw;       /* resampled size */
+    int32_t top, left;    /* position of the resampled image in the canvas */
+    int32_t reserved;
+} ydet_u8_image;
+typedef struct {
+    int32_t N, out_h, out_w;
+    int32_t out_dtype, layout, swap_rb, scale_mode;
+    int32_t pad_value[3]; /* per source channel, 0..255 */
+    float mean[3], std[3];/* per source channel (scale_mode 2) */
+} ydet_preproc_desc;
+int ydet_preprocess_u8(const ydet_u8_image* images /* device, N entries */, const ydet_preproc_desc* d /* host */,
+                       void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Launch-list executor: one call runs a whole pre-planned forward pass

@@ -448,3 +448,28 @@ def test_val_run_device_tail_matches_host_recomputation():
     p, r, ap, f1, _ = U.ap_per_class(*stats)
     assert stats[0].any() and 0.0 < map50 <= 1.0
     np.testing.assert_allclose([mp, mr, map50, map95], [p.mean(), r.mean(), ap[:, 0].mean(), ap.mean()], rtol=1e-6)
+
+
+def test_autoshape_numpy_images_match_manual_pipeline():
+    """AutoShape on a list of RGB uint8 images (reference yolov5_official/utils.py:1727-1762): the device
+    pre-processing feeds the same tensor the host chain would build, so the detections equal the manual pipeline's."""
+    from oracle import preproc as OP
+    from yolo_amd.yolov5_official import utils as U
+    engine.set_compute_dtype("fp32")
+    m = build_v5s(20).to(DEV)
+    auto = m.autoshape()
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, size=s + (3,), dtype=np.uint8) for s in ((120, 160), (90, 200), (64, 64))]
+    det = auto([im.copy() for im in imgs], size=128)
+    assert det.n == 3 and det.s[0] == 3
+    shape1 = (int(det.s[2]), int(det.s[3]))
+    assert shape1[0] % 32 == 0 and shape1[1] % 32 == 0
+    x = np.stack([np.ascontiguousarray(OP.letterbox(im, shape1, auto=False)[0].transpose(2, 0, 1)) for im in imgs])
+    xt = torch.from_numpy(x).to(DEV).float() / 255.
+    y = U.non_max_suppression(m(xt)[0], auto.conf, iou_thres=auto.iou, classes=None, max_det=auto.max_det)
+    for i, im in enumerate(imgs):
+        U.scale_coords(shape1, y[i][:, :4], im.shape[:2])
+        assert torch.equal(det.pred[i], y[i])
+        assert det.xywh[i].shape == y[i].shape and det.xyxyn[i].shape == y[i].shape
+    out = auto(xt)                  # tensor batches go straight through the model, as in the reference
+    assert isinstance(out, tuple) and out[0].shape[0] == 3

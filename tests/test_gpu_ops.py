@@ -534,3 +534,76 @@ def test_process_batch_golden_and_batched(golden):
         np.testing.assert_array_equal(got[b, :n], ref, err_msg=f"image {b}")
         assert not got[b, n:].any()
     assert got[0, 0].any() and not got[0, 1].any()
+
+
+# ---- pre-processing: uint8 HWC images -> network input, one launch (ydet_preprocess_u8) ------------------------------
+PRE_SHAPES = [(480, 640), (375, 500), (720, 1280), (1280, 1280), (37, 53), (640, 640), (333, 500), (1, 1), (12, 900)]
+
+
+def _u8_images(shapes, seed=0):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, size=s + (3,), dtype=np.uint8) for s in shapes]
+
+
+@pytest.mark.parametrize("new_shape", [(640, 640), (416, 416), (96, 160)])
+def test_letterbox_batch_matches_oracle(new_shape):
+    """Bit-exact against the CPU restatement: same fixed-point resampling, border, BGR->RGB, CHW, IEEE / 255."""
+    from oracle import preproc as OP
+    from yolo_amd.preprocess import letterbox_batch
+    imgs = _u8_images(PRE_SHAPES, seed=new_shape[0])
+    x, ratios, pads = letterbox_batch(imgs, new_shape=new_shape, auto=False, device=DEV)
+    assert x.shape == (len(imgs), 3) + new_shape and x.dtype == torch.float32
+    for i, im in enumerate(imgs):
+        np.testing.assert_array_equal(x[i].cpu().numpy(), OP.v5_input(im, new_shape, auto=False), err_msg=str(im.shape))
+        _, r, p = OP.letterbox(im, new_shape, auto=False)
+        assert tuple(ratios[i]) == tuple(r) and tuple(pads[i]) == tuple(p)
+    xb, _, _ = letterbox_batch(imgs[:3], new_shape=new_shape, auto=False, device=DEV, dtype=torch.bfloat16)
+    assert torch.equal(xb, x[:3].to(torch.bfloat16))
+
+
+def test_base_transform_batch_matches_oracle():
+    from oracle import preproc as OP
+    from yolo_amd.data.transformers import BaseTransform
+    imgs = _u8_images(PRE_SHAPES, seed=7)
+    for size in (416, 64):
+        bt = BaseTransform(size)
+        x = bt.batch(imgs, device=DEV)
+        assert x.shape == (len(imgs), 3, size, size)
+        for i, im in enumerate(imgs):
+            np.testing.assert_array_equal(x[i].cpu().numpy(), OP.family_a_input(im, size, bt.mean, bt.std), err_msg=str(im.shape))
+
+
+def test_preproc_golden(golden):
+    """The reference's own letterbox / base_transform outputs (recorded with the restated resize standing in for cv2)."""
+    from yolo_amd.data.transformers import BaseTransform
+    from yolo_amd.yolov5_official.utils import letterbox
+    import json
+    g = golden("g10_preproc")
+    for i in range(int(g["n_lb"])):
+        kw = json.loads(str(g[f"lb{i}_kw"]))
+        out, ratio, pad = letterbox(torch.from_numpy(g[f"lb{i}_img"]).to(DEV), tuple(int(v) for v in g[f"lb{i}_new_shape"]), **kw)
+        np.testing.assert_array_equal(out.cpu().numpy(), g[f"lb{i}_out"])
+        np.testing.assert_array_equal(np.array(ratio, np.float64), g[f"lb{i}_ratio"])
+        np.testing.assert_array_equal(np.array(pad, np.float64), g[f"lb{i}_pad"])
+    for i in range(int(g["n_bt"])):
+        x, b, l = BaseTransform(int(g[f"bt{i}_size"]))(g[f"bt{i}_img"])
+        assert b is None and l is None
+        np.testing.assert_array_equal(x.cpu().numpy(), g[f"bt{i}_out"])
+
+
+def test_preproc_strided_source_and_errors():
+    from oracle import preproc as OP
+    from yolo_amd.preprocess import letterbox_batch, preprocess_u8
+    big = torch.from_numpy(_u8_images([(200, 300)], seed=3)[0]).to(DEV)
+    crop = big[10:150, 20:260]                      # rows keep the parent's pitch
+    x, _, _ = letterbox_batch([crop], new_shape=(128, 128), auto=False)
+    np.testing.assert_array_equal(x[0].cpu().numpy(), OP.v5_input(crop.cpu().numpy(), (128, 128), auto=False))
+    assert letterbox_batch([], new_shape=(64, 64), device=DEV)[0].shape == (0, 3, 64, 64)
+    with pytest.raises(RuntimeError):
+        preprocess_u8([big.cpu()], [(8, 8, 0, 0)], (8, 8), device="cpu")
+    with pytest.raises(ValueError):
+        preprocess_u8([big], [(80, 80, 0, 0)], (64, 64))
+    with pytest.raises(TypeError):
+        preprocess_u8([big.float()], [(8, 8, 0, 0)], (8, 8))
+    with pytest.raises(ValueError):                 # auto=True pads to different canvases
+        letterbox_batch(_u8_images([(480, 640), (640, 480)]), new_shape=(640, 640), auto=True, device=DEV)

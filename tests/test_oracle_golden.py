@@ -198,3 +198,45 @@ def test_voc_metric(golden):
         ap = OM.voc_eval_lines(lines, recs, npos, 0.5, True)[2]
         assert abs(ap - float(g["aps"][ci])) < 1e-12, cname
     assert float(g["aps"][3]) == -1.0  # the undetected class contributes -1 to the mean
+
+
+# ---- G10: pre-processing (letterbox / base_transform) ---------------------------------------------------
+def test_resize_known_answers():
+    """Hand-computed values of the 11-bit fixed-point bilinear arithmetic, plus its invariants."""
+    from oracle import preproc as OP
+    row = np.array([[[0, 0, 0], [255, 255, 255]]], np.uint8)
+    # scale 0.5: samples at -0.25 (edge: 0), 0.25 (1536/512), 0.75 (512/1536), 1.25 (edge: 255)
+    np.testing.assert_array_equal(OP.resize_linear_u8(row, (4, 1))[0, :, 0], [0, 64, 191, 255])
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(12, 10, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(OP.resize_linear_u8(img, (10, 12)), img)                      # same size: copy
+    box = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    np.testing.assert_array_equal(OP.resize_linear_u8(img, (5, 6)), box)                        # exact half: box mean
+    flat = np.full((7, 9, 3), 201, np.uint8)
+    for d in ((20, 31), (4, 3), (9, 30)):
+        assert (OP.resize_linear_u8(flat, d) == 201).all()                                      # constants survive
+    up = OP.resize_linear_u8(img, (23, 29))
+    assert up.shape == (29, 23, 3) and up.min() >= img.min() and up.max() <= img.max()
+
+
+def test_preproc_geometry_and_pixels_golden(golden):
+    from oracle import preproc as OP
+    from yolo_amd import preprocess as P
+    g = golden("g10_preproc")
+    for i in range(int(g["n_lb"])):
+        img, kw = g[f"lb{i}_img"], json.loads(str(g[f"lb{i}_kw"]))
+        new_shape = tuple(int(v) for v in g[f"lb{i}_new_shape"])
+        for geo in (OP.letterbox_geometry, P.letterbox_geometry):      # the checker and the product's host logic
+            new_unpad, ratio, pad, top, bottom, left, right = geo(img.shape[:2], new_shape, **kw)
+            if tuple(g[f"lb{i}_resize"]) != (-1, -1):
+                assert tuple(new_unpad) == tuple(g[f"lb{i}_resize"]), i
+            else:
+                assert tuple(new_unpad) == img.shape[:2][::-1], i
+            assert (top, bottom, left, right) == tuple(g[f"lb{i}_border"]), i
+            np.testing.assert_array_equal(np.array(ratio, np.float64), g[f"lb{i}_ratio"])
+            np.testing.assert_array_equal(np.array(pad, np.float64), g[f"lb{i}_pad"])
+        out, ratio, pad = OP.letterbox(img, new_shape, **kw)
+        np.testing.assert_array_equal(out, g[f"lb{i}_out"])
+    for i in range(int(g["n_bt"])):
+        x = OP.base_transform(g[f"bt{i}_img"], int(g[f"bt{i}_size"]), g[f"bt{i}_mean"], g[f"bt{i}_std"])
+        np.testing.assert_array_equal(x, g[f"bt{i}_out"])

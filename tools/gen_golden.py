@@ -409,6 +409,56 @@ def main():
     save("g7_voc", aps=np.array(aps), aps_area=np.array(aps_area), map=ev.map, labelmap=np.array(labelmap), names=np.array(names),
          gts=np.array(json.dumps(gts)), voc_ap07=ev.voc_ap(rec, prec, True), voc_ap_area=ev.voc_ap(rec, prec, False), **flat)
 
+    # ================= G10: pre-processing (yolov5_official/utils.py:40-75, data/transformers.py:456-471) ==========
+    # cv2 is not installed: the reference's letterbox / base_transform run with cv2.resize = the oracle's restatement
+    # of OpenCV's 8-bit bilinear path and cv2.copyMakeBorder = a constant pad, both behind recorders.  What is pinned is
+    # everything the reference itself computes: resize target, border widths, ratio / pad, colour, normalisation.
+    from oracle import preproc as OP
+    sys.modules["torchvision"].transforms = types.ModuleType("torchvision.transforms")   # imported, never used on this path
+    import data.transformers as rtf
+    cv2 = sys.modules["cv2"]
+    calls = []
+    def _resize(img, dsize, interpolation=None):
+        calls.append(("resize", tuple(int(v) for v in dsize), interpolation))
+        return OP.resize_linear_u8(img, dsize)
+    def _border(img, top, bottom, left, right, kind, value=None):
+        calls.append(("border", (top, bottom, left, right), tuple(value)))
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, 3), np.uint8)
+        out[:] = np.asarray(value, np.uint8)
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+    cv2.resize, cv2.copyMakeBorder, cv2.INTER_LINEAR, cv2.BORDER_CONSTANT = _resize, _border, 1, 0
+    rutils.cv2 = cv2
+    rtf.cv2 = cv2
+    gp = np.random.default_rng(10)
+    pre = {}
+    lb_cases = [((120, 160), (160, 160), dict(auto=False)), ((75, 100), (160, 160), dict(auto=True)),
+                ((90, 160), (96, 96), dict(auto=False)), ((192, 192), (96, 96), dict(auto=False)),
+                ((100, 37), (96, 64), dict(auto=False, scaleup=False)), ((67, 100), 96, dict(auto=False, scaleFill=True)),
+                ((64, 64), (64, 64), dict(auto=False)), ((37, 53), (128, 160), dict(auto=False)),
+                ((125, 88), (160, 160), dict(auto=True, stride=64))]
+    for i, (shape, new_shape, kw) in enumerate(lb_cases):
+        img = gp.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+        calls.clear()
+        out, ratio, pad = rutils.letterbox(img.copy(), new_shape=new_shape, **kw)
+        rs = [c for c in calls if c[0] == "resize"]
+        bd = [c for c in calls if c[0] == "border"][0]
+        pre[f"lb{i}_img"], pre[f"lb{i}_out"] = img, out
+        pre[f"lb{i}_new_shape"] = np.array(new_shape if isinstance(new_shape, tuple) else (new_shape, new_shape))
+        pre[f"lb{i}_kw"] = np.array(json.dumps(kw))
+        pre[f"lb{i}_resize"] = np.array(rs[0][1] if rs else (-1, -1))
+        pre[f"lb{i}_border"] = np.array(bd[1])
+        pre[f"lb{i}_ratio"], pre[f"lb{i}_pad"] = np.array(ratio, np.float64), np.array(pad, np.float64)
+    pre["n_lb"] = len(lb_cases)
+    for i, (shape, size) in enumerate([((75, 100), 96), ((120, 160), 64), ((128, 128), 64), ((20, 30), 64)]):
+        img = gp.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+        bt = rtf.BaseTransform(size)
+        x, _, _ = bt(img.copy())
+        pre[f"bt{i}_img"], pre[f"bt{i}_out"], pre[f"bt{i}_size"] = img, x, size
+        pre[f"bt{i}_mean"], pre[f"bt{i}_std"] = bt.mean, bt.std
+    pre["n_bt"] = 4
+    save("g10_preproc", **pre)
+
     # ================= G8: structure (state_dict keys + shapes) =======================================
     struct = {}
     def keys_of(model):

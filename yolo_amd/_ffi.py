@@ -9,13 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libydet.so")
 
-F32, BF16 = 0, 1
+F32, BF16, U8 = 0, 1, 2   # U8: output dtype of ydet_preprocess_u8 only
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
  OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK) = range(12)
 MAX_ANCHORS = 8
-ABI_VERSION = 6   # YDET_ABI_VERSION of include/ydet.h these structs were written against
+ABI_VERSION = 7   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -67,6 +67,17 @@ class HeadDesc(C.Structure):
     ]
 
 
+class U8Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("pitch", C.c_int32), ("rh", C.c_int32),
+                ("rw", C.c_int32), ("top", C.c_int32), ("left", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PreprocDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_dtype", C.c_int32),
+                ("layout", C.c_int32), ("swap_rb", C.c_int32), ("scale_mode", C.c_int32),
+                ("pad_value", C.c_int32 * 3), ("mean", C.c_float * 3), ("std", C.c_float * 3)]
+
+
 class Op(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("iarg", C.c_int32), ("iarg2", C.c_int32), ("iarg3", C.c_int32),
@@ -104,6 +115,7 @@ SYMBOLS = {
     "ydet_nms_perclass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ydet_box_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ydet_preprocess_u8": (C.c_int, [C.c_void_p, C.POINTER(PreprocDesc), C.c_void_p, C.c_void_p]),
     "ydet_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "ydet_run_op_lists": (C.c_int, [C.POINTER(C.POINTER(Op)), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
     "ydet_timer_create": (C.c_void_p, [C.c_int]),

@@ -3,6 +3,8 @@
 `non_max_suppression` and `box_iou` run on the GPU through libydet.so; the box-format helpers and the
 AP bookkeeping are small host-side numpy/torch routines, as in the reference.
 """
+import math
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -198,19 +200,82 @@ def fuse_conv_and_bn(conv, bn):
     return fused
 
 
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor                                            # reference :981-983
+
+
+def letterbox(img, new_shape=(640, 640), color=(114, 114, 114), auto=True, scaleFill=False, scaleup=True, stride=32):
+    """Resize + pad one uint8 HWC image to `new_shape` keeping its aspect ratio (reference :40-75); the pixels are
+    produced on the GPU.  Returns (uint8 HWC CUDA tensor, ratio, (dw, dh))."""
+    from ..preprocess import letterbox_geometry, preprocess_u8
+    new_unpad, ratio, pad, top, bottom, left, right = letterbox_geometry(tuple(img.shape[:2]), new_shape, auto,
+                                                                         scaleFill, scaleup, stride)
+    out_hw = (new_unpad[1] + top + bottom, new_unpad[0] + left + right)
+    x = preprocess_u8([img], [(new_unpad[0], new_unpad[1], left, top)], out_hw, pad_value=color, scale_mode=0,
+                      dtype=torch.uint8, channels_last=True)
+    return x[0], ratio, pad
+
+
+class Detections:
+    """Per-image results of AutoShape (data fields of reference :1765-1780; the display helpers are not part of
+    the inference path)."""
+
+    def __init__(self, imgs, pred, files, names=None, shape=None):
+        d = pred[0].device
+        gn = [torch.tensor([*[im.shape[i] for i in [1, 0, 1, 0]], 1., 1.], device=d) for im in imgs]
+        self.imgs, self.pred, self.names, self.files = imgs, pred, names, files
+        self.xyxy = pred
+        self.xywh = [xyxy2xywh(x) for x in pred]
+        self.xyxyn = [x / g for x, g in zip(self.xyxy, gn)]
+        self.xywhn = [x / g for x, g in zip(self.xywh, gn)]
+        self.n = len(self.pred)
+        self.s = shape
+
+    def __len__(self):
+        return self.n
+
+
 class AutoShape(nn.Module):
-    """Thin input-robust wrapper: tensors in, NMS'ed detections out (tensor branch of reference :1697-1762).
-    Image-file / PIL / numpy inputs need cv2 letterboxing, which lives outside the accelerated path."""
+    """Input-robust wrapper (reference :1697-1762).  A tensor batch goes straight through the model, as in the
+    reference.  numpy HWC / CHW images (RGB, uint8) are letterboxed to a common stride-multiple shape, scaled by
+    1/255 and stacked by ONE pre-processing launch on the GPU, then model -> NMS -> boxes mapped back to each
+    image's own pixels.  File names, URLs and PIL images need decoders that live outside this package."""
     conf, iou, classes, max_det = 0.25, 0.45, None, 1000
 
     def __init__(self, model):
         super().__init__()
         self.model = model.eval()
+        self.stride = getattr(model, "stride", torch.tensor([32.]))
+        self.names = getattr(model, "names", None)
+
+    def autoshape(self):
+        return self
 
     @torch.no_grad()
     def forward(self, imgs, size=640, augment=False, profile=False):
-        if not isinstance(imgs, torch.Tensor):
-            raise NotImplementedError("AutoShape: only torch.Tensor batches are supported")
+        from ..preprocess import letterbox_batch
         p = next(self.model.parameters())
-        y = self.model(imgs.to(p.device).type_as(p), augment)[0]
-        return non_max_suppression(y, self.conf, iou_thres=self.iou, classes=self.classes, max_det=self.max_det)
+        if isinstance(imgs, torch.Tensor):
+            return self.model(imgs.to(p.device).type_as(p), augment)
+        n, imgs = (len(imgs), list(imgs)) if isinstance(imgs, (list, tuple)) else (1, [imgs])
+        shape0, shape1, files = [], [], []
+        for i, im in enumerate(imgs):
+            if not isinstance(im, np.ndarray):
+                raise NotImplementedError("AutoShape: pass numpy images or a tensor batch (file / URL / PIL inputs "
+                                          "need an image decoder)")
+            if im.shape[0] < 5:
+                im = im.transpose((1, 2, 0))
+            im = im[..., :3] if im.ndim == 3 else np.tile(im[..., None], 3)
+            s = im.shape[:2]
+            shape0.append(s)
+            g = size / max(s)
+            shape1.append([y * g for y in s])
+            imgs[i] = np.ascontiguousarray(im)
+            files.append(f"image{i}.jpg")
+        shape1 = [make_divisible(x, int(torch.as_tensor(self.stride).max())) for x in np.stack(shape1, 0).max(0)]
+        x, _, _ = letterbox_batch(imgs, new_shape=shape1, auto=False, bgr_to_rgb=False, device=p.device)
+        y = self.model(x.type_as(p), augment)[0]
+        y = non_max_suppression(y, self.conf, iou_thres=self.iou, classes=self.classes, max_det=self.max_det)
+        for i in range(n):
+            scale_coords(shape1, y[i][:, :4], shape0[i])
+        return Detections(imgs, y, files, self.names, x.shape)
