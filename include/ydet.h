@@ -266,6 +266,20 @@ int ydet_box_iou(const float* a, int na, const float* b, int nb, float* iou, voi
 int ydet_process_batch(const float* det, const int32_t* count, int B, int max_det, const float* labels,
                        const int32_t* label_start, const float* iouv, int niou, uint8_t* correct, void* stream);
 
+/* The detection-to-ground-truth matching of the VOC metric: data/vocapi_evaluator.py:284-318 (the loop over one
+ * class's detections in descending confidence inside voc_eval), for every class and image of an evaluation in one
+ * launch.  A group is one (class, image) pair.  boxes [n_det, 4] float64 xyxy as the reference reads them back from
+ * its result files; members [n_det] lists detection indices group by group, inside a group in the order the reference
+ * visits them (descending confidence; the caller's argsort fixes ties); group_start [n_groups + 1] offsets into
+ * members; gt_boxes [m, 4] float64 / gt_difficult [m] grouped the same way with offsets gt_start [n_groups + 1].
+ * flags [n_det] (indexed by detection): 1 true positive, 2 false positive, 0 neither (best box is "difficult").
+ * Overlaps are float64, the best box is the first maximum, a NaN overlap wins the maximum and is a false positive,
+ * exactly as the numpy expressions of the reference behave.  workspace: ydet_voc_match_workspace_bytes(n_det). */
+size_t ydet_voc_match_workspace_bytes(int n_det);
+int ydet_voc_match(const double* boxes, int n_det, const int32_t* members, const int32_t* group_start, int n_groups,
+                   const double* gt_boxes, const uint8_t* gt_difficult, const int32_t* gt_start, double ovthresh,
+                   uint8_t* flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Image pre-processing: a batch of uint8 HWC images (3 interleaved channels, any sizes) -> the network input.
  * Replaces the host chain  letterbox (yolov5_official/utils.py:40-75: cv2.resize INTER_LINEAR + cv2.copyMakeBorder

@@ -607,3 +607,65 @@ def test_preproc_strided_source_and_errors():
         preprocess_u8([big.float()], [(8, 8, 0, 0)], (8, 8))
     with pytest.raises(ValueError):                 # auto=True pads to different canvases
         letterbox_batch(_u8_images([(480, 640), (640, 480)]), new_shape=(640, 640), auto=True, device=DEV)
+
+
+# ---- VOC metric: the matching loop on the device (ydet_voc_match) ----------------------------------------------------
+def _voc_random_case(seed, n_img=40, n_cls=5):
+    rng = np.random.default_rng(seed)
+    names = [f"img{i:03d}" for i in range(n_img)]
+    labelmap = [f"c{j}" for j in range(n_cls)]
+    recs, boxes = {}, [[np.empty((0, 5), np.float32) for _ in names] for _ in labelmap]
+    for ii, n in enumerate(names):
+        objs = []
+        for _ in range(int(rng.integers(0, 7))):
+            x, y = rng.integers(0, 300, 2)
+            w, h = rng.integers(0, 120, 2)          # zero-area ground truth happens
+            objs.append({"name": labelmap[int(rng.integers(0, n_cls - 1))], "difficult": int(rng.random() < 0.25),
+                         "bbox": [int(x), int(y), int(x + w), int(y + h)]})
+        recs[n] = objs
+        for ci in range(n_cls - 1):                 # the last class never has detections (-1)
+            k = int(rng.integers(0, 25))
+            if k == 0:
+                continue
+            d = np.zeros((k, 5), np.float32)
+            src = [o["bbox"] for o in objs if o["name"] == labelmap[ci]]
+            for r in range(k):
+                if src and rng.random() < 0.7:      # near-duplicates of a ground-truth box: contested claims
+                    b = np.array(src[int(rng.integers(0, len(src)))], np.float32) - 1 + rng.normal(0, 4, 4).astype(np.float32)
+                else:
+                    p = rng.uniform(0, 300, 2)
+                    b = np.concatenate([p, p + rng.uniform(0, 100, 2)]).astype(np.float32)
+                if rng.random() < 0.05:
+                    b[2:] = b[:2]                   # zero-area detection on a zero-area box: 0/0
+                d[r, :4] = b
+                d[r, 4] = np.float32(int(rng.integers(0, 40)) / 40.0) if rng.random() < 0.5 else rng.random()   # score ties
+            boxes[ci][ii] = d
+    return names, labelmap, recs, boxes
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_voc_matching_on_device_equals_host_loop(seed):
+    from yolo_amd.data import vocapi_evaluator as V
+    names, labelmap, recs, boxes = _voc_random_case(seed)
+    for use07 in (True, False):
+        dev_aps = V.voc_eval_all_device(boxes, names, recs, labelmap, DEV, 0.5, use07)
+        host_aps = []
+        for ci, cls in enumerate(labelmap):
+            gts = {n: (np.array([o["bbox"] for o in recs[n] if o["name"] == cls], dtype=float).reshape(-1, 4),
+                       np.array([o["difficult"] for o in recs[n] if o["name"] == cls], dtype=bool)) for n in names}
+            dets = {n: V.round_like_results_file(boxes[ci][ii]) for ii, n in enumerate(names) if len(boxes[ci][ii])}
+            with np.errstate(all="ignore"):
+                host_aps.append(V.voc_eval_class(dets, gts, 0.5, use07)[2])
+        assert dev_aps == host_aps
+        assert dev_aps[-1] == -1.0
+
+
+def test_voc_metric_on_device_golden(golden):
+    """The reference's own voc_eval outputs (fixture from the imported reference), matching loop on the GPU."""
+    from test_host import _voc_fixture
+    g, ev, boxes = _voc_fixture(golden)
+    ev.device = torch.device(DEV)
+    assert abs(ev.evaluate_detections(boxes) - float(g["map"])) < 1e-12
+    np.testing.assert_allclose(ev.aps, g["aps"], rtol=0, atol=1e-12)
+    ev.evaluate_detections(boxes, use_07=False)
+    np.testing.assert_allclose(ev.aps, g["aps_area"], rtol=0, atol=1e-12)

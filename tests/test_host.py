@@ -286,3 +286,14 @@ def test_two_rank_gloo_exchange(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_results_file_rounding_without_strings():
+    """The vectorised rounding equals the reference's write-then-parse round trip ('{:.3f}' score, '{:.1f}' of x + 1),
+    including exact halves (x.25 -> half to even on the exact value)."""
+    from yolo_amd.data.vocapi_evaluator import round_like_results_file, round_like_results_file_fast
+    rng = np.random.default_rng(0)
+    d = np.concatenate([rng.uniform(-5, 700, size=(4000, 5)), rng.integers(-8, 2800, size=(1000, 5)) / 4.0,
+                        rng.integers(0, 4000, size=(1000, 5)) / 2000.0 + 0.0005]).astype(np.float32)
+    d[:, 4] = np.abs(d[:, 4]) % 1.0
+    np.testing.assert_array_equal(round_like_results_file_fast(d), round_like_results_file(d))

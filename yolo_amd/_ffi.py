@@ -115,6 +115,9 @@ SYMBOLS = {
     "ydet_nms_perclass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ydet_box_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ydet_voc_match_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "ydet_voc_match": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_double, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ydet_preprocess_u8": (C.c_int, [C.c_void_p, C.POINTER(PreprocDesc), C.c_void_p, C.c_void_p]),
     "ydet_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "ydet_run_op_lists": (C.c_int, [C.POINTER(C.POINTER(Op)), C.POINTER(C.c_int), C.c_int, C.c_void_p]),

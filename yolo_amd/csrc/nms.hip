@@ -766,6 +766,56 @@ __global__ __launch_bounds__(256) void process_batch_kernel(const float* det, co
     }
 }
 
+// VOC detection-to-ground-truth matching (data/vocapi_evaluator.py:284-318) for every (class, image) group of a whole
+// evaluation in one launch.  The reference walks one class's detections in descending confidence and, per detection,
+// takes the ground-truth box of its image with the largest overlap (float64, first maximum, NaN wins as in numpy):
+// overlap > thr and the box is not "difficult": true positive if no earlier detection claimed the box, else false
+// positive; overlap not above thr: false positive; a difficult box: neither.  Claims never cross images, and whether a
+// detection claims depends only on the earlier detections whose best box is the same one, so each detection finds its
+// best box independently (phase 1) and then looks back over its group (phase 2).  One workgroup per group.
+__global__ __launch_bounds__(256) void voc_match_kernel(const double* bb, const int32_t* members, const int32_t* grp_start,
+                                                         const double* gt, const uint8_t* difficult,
+                                                         const int32_t* gt_start, double thr, double* ws_ov,
+                                                         int32_t* ws_j, uint8_t* flags) {
+    const int g = blockIdx.x;
+    const int m0 = grp_start[g], m1 = grp_start[g + 1];
+    const int g0 = gt_start[g], g1 = gt_start[g + 1];
+    for (int i = m0 + threadIdx.x; i < m1; i += 256) {
+        const int k = members[i];
+        const double x1 = bb[4 * k], y1 = bb[4 * k + 1], x2 = bb[4 * k + 2], y2 = bb[4 * k + 3];
+        double best = -INFINITY;
+        int jbest = -1;
+        bool nan = false;
+        for (int j = g0; j < g1; ++j) {
+            const double* q = gt + 4 * (size_t)j;
+            const double iw = fmax(fmin(q[2], x2) - fmax(q[0], x1), 0.0);
+            const double ih = fmax(fmin(q[3], y2) - fmax(q[1], y1), 0.0);
+            const double inter = iw * ih;
+            const double uni = (x2 - x1) * (y2 - y1) + (q[2] - q[0]) * (q[3] - q[1]) - inter;
+            const double ov = inter / uni;
+            if (ov != ov && !nan) { nan = true; jbest = j; }      // numpy's max / argmax return the first NaN
+            if (!nan && ov > best) { best = ov; jbest = j; }
+        }
+        ws_ov[i] = nan ? (double)NAN : best;
+        ws_j[i] = jbest;
+    }
+    __syncthreads();
+    for (int i = m0 + threadIdx.x; i < m1; i += 256) {
+        const double ov = ws_ov[i];
+        const int j = ws_j[i];
+        uint8_t f = 2;                                   // false positive
+        if (ov > thr) {
+            if (difficult[j]) f = 0;
+            else {
+                f = 1;
+                for (int e = m0; e < i; ++e)
+                    if (ws_j[e] == j && ws_ov[e] > thr) { f = 2; break; }
+            }
+        }
+        flags[members[i]] = f;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t ydet_nms_v5_workspace_bytes(int N, int nboxes, int no) {
@@ -884,5 +934,29 @@ extern "C" int ydet_process_batch(const float* det, const int32_t* count, int B,
     hipLaunchKernelGGL(process_batch_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), det, count, max_det, labels,
                        label_start, iouv, niou, correct);
     YDET_CHECK_LAUNCH("process_batch_kernel");
+    return YDET_OK;
+}
+
+extern "C" size_t ydet_voc_match_workspace_bytes(int n_det) {
+    return n_det <= 0 ? 0 : (size_t)n_det * (sizeof(double) + sizeof(int32_t));
+}
+
+extern "C" int ydet_voc_match(const double* boxes, int n_det, const int32_t* members, const int32_t* group_start,
+                              int n_groups, const double* gt_boxes, const uint8_t* gt_difficult,
+                              const int32_t* gt_start, double ovthresh, uint8_t* flags, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(n_det >= 0 && n_groups >= 0, "voc_match: n_det=%d n_groups=%d", n_det, n_groups);
+    if (n_det == 0 || n_groups == 0) return YDET_OK;
+    YDET_CHECK_ARG(boxes && members && group_start && gt_start && flags, "voc_match: null pointer");
+    if (workspace_bytes < ydet_voc_match_workspace_bytes(n_det) || workspace == nullptr)
+        return fail(YDET_ERR_WORKSPACE, "voc_match: workspace of %zu bytes, need %zu", workspace_bytes,
+                    ydet_voc_match_workspace_bytes(n_det));
+    YDET_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "voc_match: workspace must be 8-byte aligned");
+    double* ws_ov = reinterpret_cast<double*>(workspace);
+    int32_t* ws_j = reinterpret_cast<int32_t*>(ws_ov + n_det);
+    hipLaunchKernelGGL(voc_match_kernel, dim3((unsigned)n_groups), dim3(256), 0, as_stream(stream), boxes, members,
+                       group_start, gt_boxes, gt_difficult, gt_start, ovthresh, ws_ov, ws_j, flags);
+    YDET_CHECK_LAUNCH("voc_match_kernel");
     return YDET_OK;
 }

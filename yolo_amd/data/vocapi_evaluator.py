@@ -34,9 +34,11 @@ def voc_ap(rec, prec, use_07_metric=True):
 
 
 def round_like_results_file(dets):
-    """[n,5] (x1,y1,x2,y2,score) -> what the reference reads back from its result files (:149-152)."""
-    dets = np.asarray(dets, dtype=np.float64).reshape(-1, 5)
-    out = np.empty_like(dets)
+    """[n,5] (x1,y1,x2,y2,score) -> what the reference reads back from its result files (:149-152).  The `+ 1` is
+    done in the array's own dtype, as the reference's `dets[k, 0] + 1` is (float32 for the evaluator's boxes)."""
+    dets = np.asarray(dets)
+    dets = dets.reshape(-1, 5) if dets.dtype == np.float32 else dets.astype(np.float64).reshape(-1, 5)
+    out = np.empty(dets.shape, dtype=np.float64)
     for k in range(dets.shape[0]):
         out[k, 4] = float("{:.3f}".format(dets[k, 4]))
         for j in range(4):
@@ -88,6 +90,85 @@ def voc_eval_class(dets_per_image, gt_per_image, ovthresh=0.5, use_07_metric=Tru
     return rec, prec, voc_ap(rec, prec, use_07_metric)
 
 
+def round_like_results_file_fast(dets):
+    """round_like_results_file without the per-value string formatting: for float32 inputs x*10 and x*1000 are exact
+    in float64, so rint (half to even, as the decimal formatter rounds the exact value) followed by the division gives
+    the double nearest to the printed decimal -- the value float() parses back."""
+    d = np.asarray(dets)
+    if d.dtype != np.float32:
+        return round_like_results_file(d)
+    d = d.astype(np.float64).reshape(-1, 5)
+    out = np.empty_like(d)
+    out[:, :4] = np.rint((d[:, :4].astype(np.float32) + np.float32(1)).astype(np.float64) * 10.0) / 10.0
+    out[:, 4] = np.rint(d[:, 4] * 1000.0) / 1000.0
+    return out
+
+
+def voc_eval_all_device(box_list, names, recs, labelmap, device, ovthresh=0.5, use_07_metric=True):
+    """voc_eval for every class with the matching loop on the GPU (one ydet_voc_match launch for the whole
+    evaluation).  box_list[class][image] = [k, 5] detections; recs[name] = parse_rec-style objects.  Returns the list
+    of per-class APs (-1 for a class without detections), equal to voc_eval_class's."""
+    from .. import ops
+    n_img = len(names)
+    bb_all, members, grp_start, gt_all, diff_all, gt_start = [], [], [0], [], [], [0]
+    per_class = []      # (offset of the class's detections in bb_all, count, npos)
+    off = 0
+    for ci, cls in enumerate(labelmap):
+        gts = []
+        for n in names:
+            objs = [o for o in recs[n] if o["name"] == cls]
+            gts.append((np.array([o["bbox"] for o in objs], dtype=np.float64).reshape(-1, 4),
+                        np.array([o["difficult"] for o in objs], dtype=bool)))
+        npos = int(sum((~g[1]).sum() for g in gts))
+        img_of, dets = [], []
+        for ii in range(n_img):
+            d = box_list[ci][ii]
+            if len(d):
+                r = round_like_results_file_fast(d)
+                dets.append(r)
+                img_of.append(np.full(len(r), ii, dtype=np.int64))
+        if not dets:
+            per_class.append((off, 0, npos))
+            continue
+        dets, img_of = np.concatenate(dets), np.concatenate(img_of)
+        order = np.argsort(-dets[:, 4])            # the reference's call: its tie order is this numpy's
+        dets, img_of = dets[order], img_of[order]  # position = rank
+        by_img = np.argsort(img_of, kind="stable") # ranks grouped by image, ascending rank inside an image
+        counts = np.bincount(img_of, minlength=n_img)
+        members.append(by_img + off)
+        pos = 0
+        for ii in range(n_img):
+            if counts[ii]:
+                pos += int(counts[ii])
+                grp_start.append(off + pos)
+                gt_all.append(gts[ii][0])
+                diff_all.append(gts[ii][1])
+                gt_start.append(gt_start[-1] + len(gts[ii][0]))
+        bb_all.append(dets[:, :4])
+        per_class.append((off, len(dets), npos))
+        off += len(dets)
+    if off == 0:
+        return [-1.0] * len(labelmap)
+    dev = torch.device(device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    flags = ops.voc_match(t(np.concatenate(bb_all), torch.float64), t(np.concatenate(members), torch.int32),
+                          t(np.array(grp_start), torch.int32),
+                          t(np.concatenate(gt_all).reshape(-1, 4) if gt_all else np.zeros((0, 4)), torch.float64),
+                          t(np.concatenate(diff_all) if diff_all else np.zeros(0, bool), torch.uint8),
+                          t(np.array(gt_start), torch.int32), ovthresh).cpu().numpy()
+    aps = []
+    for o, n, npos in per_class:
+        if n == 0:
+            aps.append(-1.0)
+            continue
+        f = flags[o:o + n]
+        tp, fp = np.cumsum((f == 1).astype(np.float64)), np.cumsum((f == 2).astype(np.float64))
+        rec = tp / float(npos)
+        prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+        aps.append(voc_ap(rec, prec, use_07_metric))
+    return aps
+
+
 def parse_rec(filename):
     """Objects of one PASCAL VOC annotation file (reference :95-112)."""
     objects = []
@@ -120,11 +201,13 @@ class VOCAPIEvaluator:
         self.dataset = dataset
         self.annotations = annotations  # optional {image name: parse_rec-style list}; else read from annopath
         self.map = None
+        self.device = None   # set by evaluate(): a CUDA device sends the matching loop of the metric to the GPU
 
     # ---- detection --------------------------------------------------------------------------------
     @torch.no_grad()
     def evaluate(self, net, batch_size=1, device="cuda"):
         net.eval()
+        self.device = torch.device(device)
         n_img = len(self.dataset)
         rank, world = ydist.world()
         lo, hi = ydist.shard_range(n_img, rank, world)
@@ -180,6 +263,12 @@ class VOCAPIEvaluator:
 
     def evaluate_detections(self, box_list, use_07=True):
         names, recs = self._ground_truth()
+        if self.device is not None and self.device.type == "cuda":
+            aps = voc_eval_all_device(box_list, names, recs, self.labelmap, self.device, 0.5, use_07)
+            if self.display:
+                for cls, ap in zip(self.labelmap, aps):
+                    print("AP for {} = {:.4f}".format(cls, ap))
+            return self._finish(aps)
         aps = []
         for ci, cls in enumerate(self.labelmap):
             gts = {}
@@ -195,6 +284,9 @@ class VOCAPIEvaluator:
             aps.append(voc_eval_class(dets, gts, 0.5, use_07)[2])
             if self.display:
                 print("AP for {} = {:.4f}".format(cls, aps[-1]))
+        return self._finish(aps)
+
+    def _finish(self, aps):
         self.aps = aps
         self.map = float(np.mean(aps))
         rank, _ = ydist.world()

@@ -189,3 +189,31 @@ def process_batch(det, count, labels, label_start, iouv):
                                           label_start.data_ptr(), iouv.data_ptr(), iouv.numel(), out.data_ptr(),
                                           _ffi.current_stream()), "ydet_process_batch")
     return out.bool()
+
+
+def voc_match(boxes, members, group_start, gt_boxes, gt_difficult, gt_start, ovthresh=0.5):
+    """The matching loop of the VOC metric (data/vocapi_evaluator.py:284-318) for all (class, image) groups in one
+    launch.  boxes [n, 4] float64; members [n] int32 (detection indices group by group, in visiting order);
+    group_start / gt_start [G + 1] int32; gt_boxes [m, 4] float64; gt_difficult [m] uint8 -- all CUDA.
+    Returns flags [n] uint8 per detection: 1 true positive, 2 false positive, 0 neither."""
+    _need_cuda(boxes, members, group_start, gt_boxes, gt_difficult, gt_start)
+    lib = _ffi.lib()
+    boxes = boxes.to(torch.float64).contiguous()
+    gt_boxes = gt_boxes.to(torch.float64).contiguous()
+    members = members.to(torch.int32).contiguous()
+    group_start = group_start.to(torch.int32).contiguous()
+    gt_start = gt_start.to(torch.int32).contiguous()
+    gt_difficult = gt_difficult.to(torch.uint8).contiguous()
+    n, G = boxes.shape[0], group_start.numel() - 1
+    assert members.numel() == n and gt_start.numel() == G + 1 and gt_boxes.shape[0] == gt_difficult.numel()
+    flags = torch.zeros(n, device=boxes.device, dtype=torch.uint8)
+    if n == 0 or G <= 0:
+        return flags
+    nbytes = lib.ydet_voc_match_workspace_bytes(n)
+    ws = torch.empty((nbytes + 7) // 8, device=boxes.device, dtype=torch.float64)
+    with torch.cuda.device(boxes.device):
+        _ffi.check(lib.ydet_voc_match(boxes.data_ptr(), n, members.data_ptr(), group_start.data_ptr(), G,
+                                      gt_boxes.data_ptr(), gt_difficult.data_ptr(), gt_start.data_ptr(), float(ovthresh),
+                                      flags.data_ptr(), ws.data_ptr(), ws.numel() * 8, _ffi.current_stream()),
+                   "ydet_voc_match")
+    return flags
