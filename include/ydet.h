@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 7
+#define YDET_ABI_VERSION 8
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -99,6 +99,14 @@ typedef struct {
      * the K step and Cout > 32; excludes res and cout_store.  NULL = one destination. */
     void* y2;
     int32_t y2_ld, y2_coff, y_split;
+    /* Optional second source of a 1x1 / stride 1 convolution: input channels [0, x_up_C) are read from the slice
+     * (x_up, x_up_ld, x_up_coff) of a map of HALF the size, pixel (h, w) taking (h/2, w/2); channels [x_up_C, Cin) come
+     * from x as usual (x keeps its layout: its first x_up_C channels are simply never read).  This is
+     * nn.Upsample(scale_factor=2, mode="nearest") followed by torch.cat and a 1x1 convolution (yolov5s.yaml head rows
+     * 11-13 and 15-17; yolov5_official/modules.py:303-310 Concat) without the upsampled map ever being written.
+     * H, W even; x_up_C and Cin multiples of the K step (32 bf16 / 16 f32); Cout > 32.  NULL = one source. */
+    const void* x_up;
+    int32_t x_up_ld, x_up_coff, x_up_C;
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 

@@ -669,3 +669,61 @@ def test_voc_metric_on_device_golden(golden):
     np.testing.assert_allclose(ev.aps, g["aps"], rtol=0, atol=1e-12)
     ev.evaluate_detections(boxes, use_07=False)
     np.testing.assert_allclose(ev.aps, g["aps_area"], rtol=0, atol=1e-12)
+
+
+# ---- nearest upsample + concat folded into the 1x1 convolution that reads them ---------------------------------------
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 10, 12, 128), (3, 128, 64, 20, 20, 256), (1, 256, 256, 7, 9, 64)])
+def test_conv_reads_upsampled_source(compute, shape):
+    """cat(upsample(a), b) -> 1x1 conv with the upsample never materialised equals the three separate ops bit for bit
+    (same operands, same accumulation order), and matches torch."""
+    N, C1, C2, h, w, Cout = shape
+    gen = _gen(11, f"up{shape}")
+    a = torch.randn(N, C1, h, w, generator=gen)
+    b = torch.randn(N, C2, 2 * h, 2 * w, generator=gen)
+    conv = nn.Conv2d(C1 + C2, Cout, 1).requires_grad_(False)
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * 0.05)
+    conv2 = nn.Conv2d(C1 + C2, 72, 1).requires_grad_(False)      # a second reader of the same concat
+
+    def build(gr, ins):
+        ta, tb = ins
+        # the sources pass through a convolution-free identity copy so that they are NHWC arena tensors
+        cat = gr.cat([gr.upsample2x(ta, 0), tb])
+        gr.to_nchw(gr.conv(cat, conv, act=_ffi.ACT_LEAKY, slope=0.1), "y")
+        gr.to_nchw(gr.conv(cat, conv2), "y2")
+
+    outs = {}
+    for fused in (True, False):
+        engine.set_upsample_fusion(fused)
+        try:
+            g = engine.Graph(DEV, compute)
+            build(g, [g.input_nchw(*a.shape), g.input_nchw(*b.shape)])
+            plan = g.finalize()
+            kinds = [k for k, _ in g.ops]
+            assert kinds.count("upsample") == (0 if fused else 1)
+            outs[fused] = plan.run(a.to(DEV), b.to(DEV))
+        finally:
+            engine.set_upsample_fusion(True)
+    for k in ("y", "y2"):
+        assert torch.equal(outs[True][k], outs[False][k]), k
+    ref = F.leaky_relu(conv(torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), b], 1)), 0.1)
+    assert rel_err(outs[True]["y"].float().cpu(), ref) < (1e-3 if compute == "fp32" else 2e-2)
+
+
+def test_upsample_is_kept_when_another_op_reads_it():
+    a = torch.randn(1, 32, 6, 6, generator=_gen(12, "keep"))
+    b = torch.randn(1, 32, 12, 12, generator=_gen(12, "keep2"))
+    conv = nn.Conv2d(64, 64, 1).requires_grad_(False)
+    conv3 = nn.Conv2d(64, 64, 3, padding=1).requires_grad_(False)
+
+    def build(gr, ins):
+        cat = gr.cat([gr.upsample2x(ins[0], 0), ins[1]])
+        gr.to_nchw(gr.conv(cat, conv), "y")
+        gr.to_nchw(gr.conv(cat, conv3), "y3")      # a 3x3 reader needs the materialised map
+
+    g = engine.Graph(DEV, "fp32")
+    build(g, [g.input_nchw(*a.shape), g.input_nchw(*b.shape)])
+    out = g.finalize().run(a.to(DEV), b.to(DEV))
+    assert [k for k, _ in g.ops].count("upsample") == 1
+    cat = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), b], 1)
+    assert rel_err(out["y"].cpu(), conv(cat)) < 1e-3 and rel_err(out["y3"].cpu(), conv3(cat)) < 1e-3

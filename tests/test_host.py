@@ -143,7 +143,7 @@ def test_planner_v5s_on_cpu():
     # 80 x 80) one kernel each, the three prediction convs decode in place
     assert kinds[0] == "focus_conv" and kinds.count("conv") == 40 and kinds.count("bottleneck") == 5
     assert kinds.count("head_decode") == 3 and "copy" not in kinds
-    assert kinds.count("spp") == 1 and kinds.count("upsample") == 2
+    assert kinds.count("spp") == 1 and kinds.count("upsample") == 0      # both upsamples ride in the 1x1 convs behind them
     bn = [op for op in plan.ops if op.kind == 11][0]          # reads cv1's own buffer, writes the first half of the concat
     assert (bn.conv.x_ld, bn.conv.x_coff, bn.conv2.y_ld, bn.conv2.y_coff, bn.conv2.res_ld) == (32, 0, 64, 0, 32)
     sib = plan.ops[1 + 1]                                     # the C3's sibling conv: cv1 -> that buffer, cv2 -> concat half 2
@@ -297,3 +297,18 @@ def test_results_file_rounding_without_strings():
                         rng.integers(0, 4000, size=(1000, 5)) / 2000.0 + 0.0005]).astype(np.float32)
     d[:, 4] = np.abs(d[:, 4]) % 1.0
     np.testing.assert_array_equal(round_like_results_file_fast(d), round_like_results_file(d))
+
+
+def test_planner_folds_nearest_upsamples_into_pointwise_convs():
+    from yolo_amd import engine
+    m = build_v5s(80)
+    for comp in ("bf16", "fp32"):
+        g = engine.Graph("cpu", comp)
+        m._lower(g, 2, 3, 640, 640)
+        assert [k for k, _ in g.ops].count("upsample") == 2
+        g.fuse_upsamples()
+        kinds = [k for k, _ in g.ops]
+        assert kinds.count("upsample") == 0
+        ups = [(a["x"].C, a["up"][1], a["up"][0].H * 2 == a["x"].H) for k, a in g.ops if k == "conv" and a.get("up")]
+        assert ups == [(512, 256, True), (256, 128, True)]
+        assert [g.ops[i][0] for i in g.ext_in] in (["focus_conv"], ["nchw2nhwc"])

@@ -61,6 +61,8 @@ struct ConvArgs {
     char* y2;         // second destination: output channels y_split.. go to y2 (slice y2_ld / y2_coff), or null
     int y2_ld, y2_coff;
     int y_split;      // INT_MAX without a second destination
+    const char* x_up; // pointwise convs only: input channels [0, up_C) are read from this map of half the size at
+    int up_ld, up_coff, up_C;   // (h/2, w/2) -- a nearest-neighbour 2x upsample that is never materialised; 0: none
 };
 
 // Detect decode of one pyramid level, done in the epilogue of its 1x1 prediction convolution (the tile holds all
@@ -439,13 +441,14 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     YDET_STAMP(23);
     const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
     const char* xsrc[XJ];
+    const char* xup[XJ];
     unsigned xmask[XJ];
     const int HoWo = a.Ho * a.Wo;
     // (image, row, column) of the tile's first pixel: one wave-uniform pair of divisions (M < 2^31, checked on the
     // host); a lane's pixels are at most BM further on, which float reciprocals resolve exactly
     int n_0 = 0, ho_0 = 0, wo_0 = 0;
     float r_wo = 0.f, r_ho = 0.f;
-    if (!pointwise) {
+    if (!pointwise || a.up_C) {
         const unsigned mu = (unsigned)m0;
         n_0 = (int)(mu / (unsigned)HoWo);
         const unsigned rem = mu - (unsigned)n_0 * (unsigned)HoWo;
@@ -462,6 +465,14 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         if (pointwise) {
             xsrc[j] = a.x + ((size_t)(okm ? m : 0) * a.x_ld + a.x_coff + lchunk * EPC) * sizeof(TIN);
             xmask[j] = okm ? 1u : 0u;
+            xup[j] = xsrc[j];
+            if (a.up_C) {      // pixel (n, ho, wo) reads (n, ho/2, wo/2) of the half-size map for its first up_C channels
+                const int cw = wo_0 + row, qw = div_small(cw, a.Wo, r_wo), wo = cw - qw * a.Wo;
+                const int ch = ho_0 + qw, qh = div_small(ch, a.Ho, r_ho), ho = ch - qh * a.Ho;
+                const int n = okm ? n_0 + qh : 0;
+                const long long pix = ((long long)n * (a.Ho >> 1) + (ho >> 1)) * (a.Wo >> 1) + (wo >> 1);
+                xup[j] = a.x_up + (pix * a.up_ld + a.up_coff + lchunk * EPC) * (long long)sizeof(TIN);
+            }
         } else {
             // no division in the tap walk either: validity of each tap is one bit of a mask
             const int cw = wo_0 + row, qw = div_small(cw, a.Wo, r_wo), wo = cw - qw * a.Wo;
@@ -486,6 +497,7 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
             xmask[j] = okm ? mk : 0u;
             const long long pix = ((long long)n * a.H + hi0) * a.W + wi0;  // may be "before" the image: masked
             xsrc[j] = a.x + (pix * a.x_ld + a.x_coff + lchunk * EPC) * (long long)sizeof(TIN);
+            xup[j] = xsrc[j];
         }
     }
     const char* zsrc = reinterpret_cast<const char*>(g_zero_chunk);
@@ -506,13 +518,14 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + woff),
                                              (__attribute__((address_space(3))) void*)(dst + j * (NW * 1024)), 16, 0, 0);
+        const bool from_up = c0 < a.up_C;      // workgroup-uniform (pointwise convs only: tap stays 0)
 #ifdef YDET_EXP_SKIP_PIX   // timing experiment only: pixel rows fetched for the first tap of each channel block only
         if (tap == 0 || a.KH == 1)
 #endif
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const bool ok = (xmask[j] >> tap) & 1u;
-            const char* src = ok ? xsrc[j] + tapoff : zsrc;
+            const char* src = ok ? (from_up ? xup[j] : xsrc[j]) + tapoff : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + WROWS * 64 + j * (NW * 1024)), 16,
                                              0, 0);
@@ -887,6 +900,7 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
         return YDET_OK;
     }
     if (a.y2) return fail(YDET_ERR_ARG, "conv: a second destination needs Cin to be a multiple of %d and at least 64 output channels", BK);
+    if (a.x_up) return fail(YDET_ERR_ARG, "conv: an upsampled source needs the LDS-DMA kernel (Cin a multiple of %d, more than 32 output channels)", BK);
     if constexpr (WARPS_N * WARPS_M != 4) {
         return fail(YDET_ERR_ARG, "conv: the %dx%d tile needs Cin to be a multiple of %d", BN, BM, BK);
     } else {
@@ -1003,6 +1017,17 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     a.cout_store = d->cout_store > 0 ? d->cout_store : d->Cout;
     a.y2 = (char*)d->y2; a.y2_ld = d->y2_ld; a.y2_coff = d->y2_coff;
     a.y_split = d->y2 ? d->y_split : 0x7fffffff;
+    a.x_up = nullptr; a.up_ld = 0; a.up_coff = 0; a.up_C = 0;
+    if (d->x_up) {
+        YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H % 2 == 0 && d->W % 2 == 0,
+                       "conv: an upsampled source needs a 1x1 convolution over an even-sized map");
+        YDET_CHECK_ARG(d->x_up_C > 0 && d->x_up_C <= d->Cin && d->x_up_C % bk == 0 && d->Cin % bk == 0 && d->Cout > 32,
+                       "conv: upsampled channels %d of %d (multiples of %d, more than 32 output channels)", d->x_up_C, d->Cin, bk);
+        YDET_CHECK_ARG(d->x_up_ld % epc == 0 && d->x_up_coff % epc == 0 && d->x_up_coff >= 0 &&
+                           d->x_up_coff + d->x_up_C <= d->x_up_ld && ((uintptr_t)d->x_up & 15) == 0,
+                       "conv: upsampled source slice (ld %d, coff %d)", d->x_up_ld, d->x_up_coff);
+        a.x_up = (const char*)d->x_up; a.up_ld = d->x_up_ld; a.up_coff = d->x_up_coff; a.up_C = d->x_up_C;
+    }
     a.vec_store = (d->Cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0 &&
                    (!d->res || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0)))
                       ? 1

@@ -197,10 +197,12 @@ class Graph:
             y, y2 = self.new(x.N, Ho, Wo, c0), self.new(x.N, Ho, Wo, c1)
             self.ops.append(("conv", dict(x=x, y=y, y2=y2, res=None, pc=pc, stride=s, pad=p, act=act,
                                           slope=float(slope), res_mode=_ffi.RES_NONE, post=None)))
+            self._tag_up(self.ops[-1][1])
             return None, [y, y2]
         out = self.new(x.N, Ho, Wo, pc.Cout)
         self.ops.append(("conv", dict(x=x, y=out, res=None, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
                                       res_mode=_ffi.RES_NONE, post=None)))
+        self._tag_up(self.ops[-1][1])
         parts, off = [], 0
         for w, _ in folded:
             parts.append(T(out.st, off, w.shape[0]))
@@ -236,6 +238,7 @@ class Graph:
             assert (res.N, res.H, res.W, res.C) == (out.N, out.H, out.W, out.C), "residual shape mismatch"
         self.ops.append(("conv", dict(x=x, y=out, res=res, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
                                       res_mode=res_mode if res is not None else _ffi.RES_NONE, post=post_rec)))
+        self._tag_up(self.ops[-1][1])
         return out
 
     def bottleneck(self, x, cv1, cv2, act=_ffi.ACT_NONE, slope=0.0, add=True, out=None):
@@ -302,7 +305,10 @@ class Graph:
         return out
 
     def upsample2x(self, x, mode):
-        return self._slice_op("upsample", x, self.new(x.N, 2 * x.H, 2 * x.W, x.C), iarg=mode)
+        out = self._slice_op("upsample", x, self.new(x.N, 2 * x.H, 2 * x.W, x.C), iarg=mode)
+        if mode == 0:
+            out.up_of = (x, self.ops[-1][1])   # nearest: fuse_upsamples() may fold it into the 1x1 convs that read it
+        return out
 
     def space_to_depth(self, x, mode):
         return self._slice_op("space2depth", x, self.new(x.N, x.H // 2, x.W // 2, 4 * x.C), iarg=mode)
@@ -326,7 +332,9 @@ class Graph:
         out = self.new(N, H, W, sum(t.C for t in ts))
         off = 0
         for t in ts:
-            self._place(t, out, off)
+            placed = self._place(t, out, off)
+            if off == 0 and placed is t and getattr(t, "up_of", None) is not None:
+                out.up_head = (t.C,) + t.up_of     # the concat starts with a nearest-upsampled map (redirected, not copied)
             off += t.C
         return out
 
@@ -336,6 +344,55 @@ class Graph:
 
     def output(self, name, t):
         self.outputs[name] = t
+
+    # ---- nearest upsample + concat folded into the 1x1 convolutions that read them ----------------------------------
+    def _tag_up(self, a):
+        """Remember on a conv record that it could read the head of its input through the half-size source."""
+        x, pc = a["x"], a["pc"]
+        head = getattr(x, "up_head", None)
+        bk = 32 if self.dt == _ffi.BF16 else 16
+        if (head is not None and (pc.KH, pc.KW, a["stride"], a["pad"]) == (1, 1, 1, 0) and x.C % bk == 0 and head[0] % bk == 0
+                and pc.Cout > 32 and x.H % 2 == 0 and x.W % 2 == 0 and x.dtype == self.dt):
+            a["up_cand"] = head
+
+    def fuse_upsamples(self):
+        """For every nearest x2 upsample whose output is the head of a concat read ONLY by 1x1 convolutions: drop the
+        upsample op and let those convolutions fetch the channels from the half-size map at (h/2, w/2) (the conv
+        kernel's second source).  The concat buffer keeps the (now unwritten) channels; no other op may read them."""
+        if not _fuse_upsample:
+            return
+
+        def reads(a):
+            return [a[k] for k in ("x", "res") if isinstance(a.get(k), T)]
+        if not any(kind == "conv" and a.get("up_cand") is not None and a.get("up") is None for kind, a in self.ops):
+            return
+        out_roots = [v.resolve()[0] for v in self.outputs.values() if isinstance(v, T)]
+        done = set()
+        for kind, a in list(self.ops):
+            cand = a.get("up_cand") if kind == "conv" else None
+            if cand is None or a.get("up") is not None or id(cand[2]) in done:
+                continue
+            C_up, src, up_rec = cand
+            done.add(id(up_rec))
+            uroot, uoff = up_rec["y"].resolve()
+            readers, ok = [], not any(r is uroot for r in out_roots)
+            for k2, a2 in self.ops:
+                if a2 is up_rec:
+                    continue
+                for t in (reads(a2) + ([a2["cv1"]["x"]] if k2 == "bottleneck" else [])):
+                    root, off = t.resolve()
+                    if root is uroot and off < uoff + C_up and uoff < off + t.C:
+                        fits = (k2 == "conv" and t is a2["x"] and off == uoff and a2.get("up_cand") is not None
+                                and a2["up_cand"][2] is up_rec)
+                        ok = ok and fits
+                        readers.append(a2)
+            if not ok or not readers:
+                continue
+            for a2 in readers:
+                a2["up"] = (src, C_up)
+            idx = next(i for i, (_, r) in enumerate(self.ops) if r is up_rec)
+            del self.ops[idx]
+            self.ext_in = [i - 1 if i > idx else i for i in self.ext_in]
 
     # ---- finalize ------------------------------------------------------------------------------
     def finalize(self, replicas=1):
@@ -354,6 +411,7 @@ class Plan:
         self.device = g.device
         self.g = g
         self.R = replicas
+        g.fuse_upsamples()
         n = len(g.ops)
         self.patch_in = list(g.ext_in)  # op indices whose source is a caller-supplied NCHW input
         self.patch_out = []       # (op index, field, storage) of external NHWC buffers
@@ -474,6 +532,11 @@ class Plan:
             r2, o2 = a["y2"].resolve()
             assert r2.dtype == ry.dtype and not r2.external
             d.y2, d.y2_ld, d.y2_coff, d.y_split = arena[r2].data_ptr(), r2.ld, o2, y.C
+        if a.get("up") is not None:
+            src, C_up = a["up"]
+            ru, ou = src.resolve()
+            assert ru.dtype == rx.dtype and not ru.external and (src.H * 2, src.W * 2, src.C) == (x.H, x.W, C_up)
+            d.x_up, d.x_up_ld, d.x_up_coff, d.x_up_C = arena[ru].data_ptr(), ru.ld, ou, C_up
         if a.get("post") is not None:
             ps, pb, pact, pslope = a["post"]
             d.post_scale, d.post_shift, d.post_act, d.post_slope = ps.data_ptr(), pb.data_ptr(), pact, pslope
@@ -560,6 +623,15 @@ class Plan:
 
 
 _batch_split = 1
+_fuse_upsample = True
+
+
+def set_upsample_fusion(flag):
+    """Whether plans fold `nearest x2 upsample -> concat -> 1x1 conv` into the convolution (default on).  Off: the
+    upsampled map is written and read back as its own op (ablation / comparison)."""
+    global _fuse_upsample
+    _fuse_upsample = bool(flag)
+
 
 
 def set_batch_split(n):
@@ -629,6 +701,8 @@ def _op_info(kind, a):
         nbytes = x.N * x.H * x.W * x.C * esz(x) + y.N * y.H * y.W * pc.Cout * esz(y) + pc.Cout * pc.KH * pc.KW * x.C * esz(x)
         if a["res"] is not None:
             nbytes += y.N * y.H * y.W * y.C * esz(x)
+        if a.get("up") is not None:     # the first C_up channels come from a map of a quarter of the pixels
+            nbytes -= x.N * x.H * x.W * a["up"][1] * esz(x) * 3 // 4
         return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W),
                     flops=flops,
                     bytes=nbytes,
