@@ -473,3 +473,43 @@ def test_autoshape_numpy_images_match_manual_pipeline():
         assert det.xywh[i].shape == y[i].shape and det.xyxyn[i].shape == y[i].shape
     out = auto(xt)                  # tensor batches go straight through the model, as in the reference
     assert isinstance(out, tuple) and out[0].shape[0] == 3
+
+
+# ---- the benchmark configurations at their full sizes ---------------------------------------------------------------
+@pytest.mark.parametrize("tag,size,batch", [("v2d19", 416, 32), ("v3spp", 608, 64), ("v4", 608, 64)])
+def test_baseline_configs_full_size(tag, size, batch):
+    """YOLOv2-D19 416 bs32, YOLOv3-SPP 608 bs64, YOLOv4 608 bs64 through size-independent properties: (a) the first and
+    last image's head maps against the CPU restatement of the network (fp32, 1e-3), (b) every image of the batch equals
+    its own single-image run bit for bit, (c) the kept set of those images is exact against the oracle's postprocess fed
+    the same decoded boxes, (d) bf16 head maps within 5e-2 of the fp32 ones."""
+    engine.set_compute_dtype("fp32")
+    net = build_fa(tag, size).to(DEV)
+    x = images(batch, size, seed=900 + size, kind="randn")
+    xd = x.to(DEV)
+    heads = [h.clone() for h in net.head_maps(xd)]
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    for i in (0, batch - 1):
+        with torch.no_grad():
+            ref = oracle_fa_heads(tag, sd, x[i:i + 1])
+        for h, r in zip(heads, ref):
+            assert rel_err(h[i].cpu().numpy(), r[0].numpy()) < 1e-3, (tag, i)
+    boxes, keep, cls, best = net.detect_batch(xd)
+    boxes, keep, cls, best = boxes.clone(), keep.clone(), cls.clone(), best.clone()
+    scores = net.decode_batch(xd)[1].clone()
+    for i in (0, batch // 2, batch - 1):
+        b1, k1, c1, s1 = net.detect_batch(xd[i:i + 1])
+        assert torch.equal(boxes[i], b1[0]) and torch.equal(keep[i], k1[0]) and torch.equal(cls[i], c1[0]) and torch.equal(best[i], s1[0])
+        bb, sc = boxes[i].cpu().numpy(), scores[i].cpu().numpy()
+        top = sc.max(1)
+        if len(np.unique(top[top >= net.conf_thresh])) != int((top >= net.conf_thresh).sum()):
+            continue        # exact score ties (saturated 1.0): numpy's visiting order is implementation-defined
+        with np.errstate(all="ignore"):
+            rb, rs, rc = O.postprocess(bb, sc, net.conf_thresh, 20, net.nms_thresh)
+        k = keep[i].bool().cpu().numpy()
+        np.testing.assert_array_equal(bb[k], rb)
+        np.testing.assert_array_equal(best[i].cpu().numpy()[k], rs)
+        np.testing.assert_array_equal(cls[i].cpu().numpy()[k], rc)
+    engine.set_compute_dtype("bf16")
+    for h, h16 in zip(heads, net.head_maps(xd)):
+        assert rel_err(h16.float().cpu().numpy(), h.cpu().numpy()) < 5e-2
+    engine.set_compute_dtype("fp32")
