@@ -381,7 +381,7 @@ template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M,
 __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     constexpr int NW = WARPS_N * WARPS_M;         // waves per workgroup (4 or 8)
     constexpr int NT = 64 * NW;
-    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "four, eight or sixteen waves per workgroup");
     constexpr int EPC = 16 / (int)sizeof(TIN);
     constexpr int BK = 4 * EPC;
     constexpr int WN = BN / WARPS_N, WM = BM / WARPS_M;
@@ -946,6 +946,10 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
             if (bn == 128 && bm == 128) return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
             if (bn == 128 && bm == 64) return launch_tile<TIN, TOUT, 128, 64, 2, 2>(a, stream);
             if (bn == 128 && bm == 256) return launch_tile<TIN, TOUT, 128, 256, 2, 4>(a, stream);
+            if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
+                if (bn == 256 && bm == 256 && a.Cout > 128 && a.Cin % 32 == 0 && a.KH * a.KW <= 32)
+                    return launch_tile<TIN, TOUT, 256, 256, 4, 4>(a, stream);
+            }
         }
     }
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
