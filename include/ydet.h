@@ -116,7 +116,9 @@ int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
  * d->x is the image [N, 3, H, W] (x_dtype, contiguous, H and W even), d->H / d->W its size, d->Cin = 3; the
  * convolution is 3x3 / stride 1 / pad 1 over the 12 focus channels, with w / bias packed as for
  * ydet_conv2d_nhwc for 16 input channels (focus channel q*3 + c, then 4 zeros; kp = 160); d->y is the NHWC bf16
- * slice [N, H/2, W/2, Cout], Cout <= 64.  bf16 weights / output only; x_ld, x_coff, res and post_* are unused. */
+ * slice [N, H/2, W/2, Cout], Cout <= 64.  bf16 weights / output only; x_ld, x_coff, res and post_* are unused.
+ * x_dtype YDET_U8: the image holds raw 0..255 pixel values and every value enters as bf16(float(v) / 255), the
+ * `img.float() / 255` of yolov5_official/val.py:68-69 folded into the load (the fp32 image is never written). */
 int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
 
 /* A residual bottleneck with C = 32 or 64 channels throughout as ONE kernel: yolov5_official/modules.py:208-218,
@@ -303,7 +305,7 @@ int ydet_voc_match(const double* boxes, int n_det, const int32_t* members, const
  * channel k shows source channel (swap_rb ? 2 - k : k).  out: [N, 3, out_h, out_w] (layout 0) or
  * [N, out_h, out_w, 3] (layout 1) of out_dtype (YDET_U8 only with scale_mode 0).
  * ------------------------------------------------------------------------------------------ */
-#define YDET_U8 2 /* output dtype of ydet_preprocess_u8 only */
+#define YDET_U8 2 /* output dtype of ydet_preprocess_u8, image dtype of ydet_focus_conv3x3_nchw */
 typedef struct {
     const uint8_t* data;  /* device pointer; pixel (y, x) channel c at data[y*pitch + 3*x + c] */
     int32_t h, w, pitch;

@@ -513,3 +513,16 @@ def test_baseline_configs_full_size(tag, size, batch):
     for h, h16 in zip(heads, net.head_maps(xd)):
         assert rel_err(h16.float().cpu().numpy(), h.cpu().numpy()) < 5e-2
     engine.set_compute_dtype("fp32")
+
+
+def test_v5s_uint8_images_equal_scaled_float_images():
+    """Raw uint8 batches (what val.py's dataloader yields) through the first kernel's 1/255 table give exactly what
+    `img.float() / 255` followed by the same network gives -- bf16 (fused first layer) and fp32 (scaled on the way in)."""
+    m = build_v5s(20).to(DEV)
+    u8 = torch.randint(0, 256, (3, 3, 96, 128), dtype=torch.uint8, generator=_gen(3, "u8img")).to(DEV)
+    for compute in ("bf16", "fp32"):
+        engine.set_compute_dtype(compute)
+        z8, x8 = m(u8)
+        zf, xf = m(u8.float() / 255.0)
+        assert torch.equal(z8, zf) and all(torch.equal(a, b) for a, b in zip(x8, xf)), compute
+    engine.set_compute_dtype("fp32")

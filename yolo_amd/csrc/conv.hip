@@ -559,8 +559,8 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         YDET_STAMP(3 + kt);
-        // every wave is past its reads of stage (kt-1)%3 == (kt+2)%3: refill it
-        if (kt + 2 < nk) issue((kt + 2) % NSTAGE);
+        // this step's operand fragments are requested first, so that their LDS latency runs under the address
+        // arithmetic and issue of the refill below instead of in front of the MFMAs
         const char* ws = smem + (kt % NSTAGE) * STAGE + (wn * WN) * 64 + fr_off;
         const char* xs = smem + (kt % NSTAGE) * STAGE + WROWS * 64 + (wm * WM) * 64 + fr_off;
         frag_t fa[FN], fb[FM];
@@ -574,6 +574,9 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 #ifdef YDET_EXP_NO_LDSREAD
         }
 #endif
+        asm volatile("" ::: "memory");   // keep the reads above the refill
+        // every wave is past its reads of stage (kt-1)%3 == (kt+2)%3: refill it
+        if (kt + 2 < nk) issue((kt + 2) % NSTAGE);
 #ifdef YDET_EXP_NO_MFMA
         if (kt == 0)
 #endif

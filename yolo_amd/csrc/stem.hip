@@ -46,9 +46,18 @@ struct Pair<__bf16> {
     }
 };
 
+// uint8 images carry raw pixel values: a pair is two bytes, and a value becomes bf16(float(v) / 255) -- the
+// `img.float() / 255` of yolov5_official/val.py:68-69 -- through a 256-entry table (IEEE division, done once per entry)
+template <>
+struct Pair<uint8_t> {
+    typedef unsigned short type;
+};
+
 template <typename TX, int FN>
 __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 F[FH * FW * 16];
+    __shared__ __bf16 lut[std::is_same<TX, uint8_t>::value ? 256 : 1];
+    if constexpr (std::is_same<TX, uint8_t>::value) lut[threadIdx.x] = (__bf16)((float)threadIdx.x / 255.0f);
     typedef typename Pair<TX>::type pair_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
             }
         }
     }
+    if constexpr (std::is_same<TX, uint8_t>::value) __syncthreads();   // the table is complete
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int fp = tid + 256 * it;
@@ -101,10 +111,15 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float v0, v1;
-                Pair<TX>::split(px[it][dy * 3 + c], v0, v1);
-                ch[dy * 3 + c] = (__bf16)v0;            // (dy, dx = 0)
-                ch[(2 + dy) * 3 + c] = (__bf16)v1;      // (dy, dx = 1)
+                if constexpr (std::is_same<TX, uint8_t>::value) {
+                    ch[dy * 3 + c] = lut[px[it][dy * 3 + c] & 0xff];
+                    ch[(2 + dy) * 3 + c] = lut[px[it][dy * 3 + c] >> 8];
+                } else {
+                    float v0, v1;
+                    Pair<TX>::split(px[it][dy * 3 + c], v0, v1);
+                    ch[dy * 3 + c] = (__bf16)v0;            // (dy, dx = 0)
+                    ch[(2 + dy) * 3 + c] = (__bf16)v1;      // (dy, dx = 1)
+                }
             }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
 
 int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {
     YDET_CHECK_ARG(d != nullptr && d->x && d->w && d->y, "focus_conv: null pointer");
-    YDET_CHECK_ARG(dtype_ok(x_dtype), "focus_conv: bad image dtype");
+    YDET_CHECK_ARG(dtype_ok(x_dtype) || x_dtype == YDET_U8, "focus_conv: bad image dtype");
     YDET_CHECK_ARG(d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "focus_conv: bf16 weights and output only");
     YDET_CHECK_ARG(d->N > 0 && d->N <= 65535 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0,
                    "focus_conv: image %d x %d x %d", d->N, d->H, d->W);
@@ -199,7 +214,7 @@ int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t str
     YDET_CHECK_ARG(d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld,
                    "focus_conv: output slice (y_ld, y_coff multiples of 8)");
     YDET_CHECK_ARG(d->res == nullptr && d->post_scale == nullptr, "focus_conv: no residual / second stage");
-    YDET_CHECK_ARG(((uintptr_t)d->x & 7) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 15) == 0 &&
+    YDET_CHECK_ARG(((uintptr_t)d->x & (x_dtype == YDET_U8 ? 1 : 7)) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 15) == 0 &&
                        ((uintptr_t)d->bias & 15) == 0, "focus_conv: pointer alignment");
     StemArgs a;
     a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
@@ -212,6 +227,9 @@ int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t str
     if (x_dtype == YDET_F32) {
         if (wide) hipLaunchKernelGGL((focus_conv3x3_kernel<float, 4>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((focus_conv3x3_kernel<float, 2>), grid, dim3(256), 0, stream, a);
+    } else if (x_dtype == YDET_U8) {
+        if (wide) hipLaunchKernelGGL((focus_conv3x3_kernel<uint8_t, 4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((focus_conv3x3_kernel<uint8_t, 2>), grid, dim3(256), 0, stream, a);
     } else {
         if (wide) hipLaunchKernelGGL((focus_conv3x3_kernel<__bf16, 4>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((focus_conv3x3_kernel<__bf16, 2>), grid, dim3(256), 0, stream, a);

@@ -560,12 +560,17 @@ class Plan:
         ext = {st: torch.empty(st.N * R, st.H, st.W, st.ld, device=self.device, dtype=_TORCH_DT[st.dtype])
                for st in self._ext_storages}
         for i, x in zip(self.patch_in, xs):
-            if x.dtype not in (torch.float32, torch.bfloat16):
+            op0 = self.op_lists[0][i]
+            focus = op0.kind == _ffi.OP_FOCUS_CONV
+            if x.dtype == torch.uint8:
+                # raw pixel values: the fused first layer scales them by 1/255 while loading (val.py:68-69 folded in);
+                # any other first layer gets the scaled fp32 image
+                if not focus:
+                    x = x.float() / 255.0
+            elif x.dtype not in (torch.float32, torch.bfloat16):
                 x = x.float()
             x = x.contiguous()
             held.append(x)
-            op0 = self.op_lists[0][i]
-            focus = op0.kind == _ffi.OP_FOCUS_CONV
             per = (op0.conv.N, op0.conv.Cin, op0.conv.H, op0.conv.W) if focus else (op0.slice.N, op0.slice.C, op0.slice.H, op0.slice.W)
             want = (per[0] * R,) + per[1:]
             assert tuple(x.shape) == want, f"plan built for {want}, got {tuple(x.shape)}"
@@ -576,7 +581,7 @@ class Plan:
                     op.conv.x = x.data_ptr() + r * step
                 else:
                     op.slice.x = x.data_ptr() + r * step
-                op.iarg3 = _ffi.BF16 if x.dtype == torch.bfloat16 else _ffi.F32
+                op.iarg3 = {torch.bfloat16: _ffi.BF16, torch.uint8: _ffi.U8}.get(x.dtype, _ffi.F32)
         for i, field, root in self.patch_out:
             t = ext[root]
             step = root.N * root.H * root.W * root.ld * t.element_size()

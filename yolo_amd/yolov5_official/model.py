@@ -313,6 +313,8 @@ class Model(engine.AcceleratedModule):
             return self.forward_augment(x)
         if x.is_cuda and not self.training:
             return self._forward_hip(x)
+        if x.dtype == torch.uint8:     # raw pixels (accepted on the accelerated path, scaled there while loading)
+            x = x.float() / 255.0
         return self.forward_once(x)
 
     def forward_once(self, x):

@@ -273,8 +273,9 @@ class AutoShape(nn.Module):
             imgs[i] = np.ascontiguousarray(im)
             files.append(f"image{i}.jpg")
         shape1 = [make_divisible(x, int(torch.as_tensor(self.stride).max())) for x in np.stack(shape1, 0).max(0)]
-        x, _, _ = letterbox_batch(imgs, new_shape=shape1, auto=False, bgr_to_rgb=False, device=p.device)
-        y = self.model(x.type_as(p), augment)[0]
+        # uint8 canvas; the model's first kernel applies the / 255 while loading (the reference's `x / 255.`, :1751)
+        x, _, _ = letterbox_batch(imgs, new_shape=shape1, auto=False, bgr_to_rgb=False, scale=False, device=p.device)
+        y = self.model(x, augment)[0]
         y = non_max_suppression(y, self.conf, iou_thres=self.iou, classes=self.classes, max_det=self.max_det)
         for i in range(n):
             scale_coords(shape1, y[i][:, :4], shape0[i])

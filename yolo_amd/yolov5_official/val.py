@@ -67,7 +67,9 @@ def run(data,
         mine = batch_i % world == rank
         if mine:
             img = img.to(dev, non_blocking=True)
-            img = (img.half() if half else img.float()) / 255.0
+            if not (img.dtype == torch.uint8 and img.is_cuda and not augment):
+                img = (img.half() if half else img.float()) / 255.0
+            # else: uint8 batches go to the model as they are; its first kernel applies the / 255 while loading
             targets = targets.to(dev).clone()
             _, _, height, width = img.shape
             out, train_out = model(img, augment=augment)
