@@ -113,7 +113,8 @@ __device__ __forceinline__ float activate(float v, int act, float slope) {
 // Four consecutive output channels of one pixel: bias, residual (either order), activation, and the optional second
 // affine + activation (a BatchNorm + activation that follows a concatenation).  MODE >= 0 fixes the variant at compile
 // time (bit 0: SiLU, else leaky with a.slope -- slope 1 is "no activation"; bit 1: second stage present; bit 2: the
-// residual goes in before the activation), so the 64 values a lane finishes run through straight-line code; MODE < 0
+// residual goes in before the activation; bit 3: there is no residual, r is not even looked at), so the 64 values a
+// lane finishes run through straight-line code; MODE < 0
 // reads the variant from the arguments (the rarely used store paths, to keep the number of instantiations down).
 // b4 / ps4 / pb4 point at the four channels' bias, post-scale and post-shift (global memory or the tile's LDS copy).
 template <int MODE>
@@ -126,9 +127,10 @@ __device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], cons
     const bool silu = MODE >= 0 ? (MODE & 1) != 0 : a.act == YDET_ACT_SILU;
     const bool post = MODE >= 0 ? (MODE & 2) != 0 : a.post_scale != nullptr;
     const bool before = MODE >= 0 ? (MODE & 4) != 0 : a.res_mode == YDET_RES_BEFORE_ACT;
+    constexpr bool nores = MODE >= 0 && (MODE & 8) != 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float x = before ? v[e] + r[e] : v[e];     // "after" and "none" share one path: r is zero without a residual
+        float x = before ? v[e] + r[e] : v[e];     // run-time form: "after" and "none" share one path (r is zero)
         if (silu) {
             // x * sigmoid(x) on the hardware exp2 / reciprocal units (relative error ~1e-6, far inside the bf16 / 1e-3
             // bars): 5 instructions instead of ~25 with an IEEE division
@@ -136,7 +138,7 @@ __device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], cons
         } else {
             x = x > 0.f ? x : x * a.slope;
         }
-        v[e] = before ? x : x + r[e];
+        v[e] = (before || nores) ? x : x + r[e];
     }
     if (post) {
         const float4 ps = *reinterpret_cast<const float4*>(ps4);
@@ -153,9 +155,15 @@ __device__ __forceinline__ void finish4(float (&v)[4], const float (&r)[4], cons
 template <typename F>
 __device__ __forceinline__ void with_epilogue_mode(const ConvArgs& a, F f) {
     const bool plain = a.post_scale == nullptr && a.res_mode != YDET_RES_BEFORE_ACT;
-    if (plain && a.act == YDET_ACT_SILU) f(std::integral_constant<int, 1>{});
-    else if (plain) f(std::integral_constant<int, 0>{});
-    else f(std::integral_constant<int, -1>{});
+    if (plain && a.act == YDET_ACT_SILU) {
+        if (a.res) f(std::integral_constant<int, 1>{});
+        else f(std::integral_constant<int, 9>{});      // most layers: no residual unpacking or masking at all
+    } else if (plain) {
+        if (a.res) f(std::integral_constant<int, 0>{});
+        else f(std::integral_constant<int, 8>{});
+    } else {
+        f(std::integral_constant<int, -1>{});
+    }
 }
 
 template <typename T>
@@ -783,7 +791,8 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                 YDET_STAMP(20);
                 // bf16 residuals of the pass are fetched up front (one memory latency for all of them instead of one
                 // per four values); fp32 residuals would double the accumulator registers and stay inline
-                constexpr bool PREFETCH_RES = sizeof(TIN) == 2;
+                constexpr bool NORES = MODE >= 0 && (MODE & 8) != 0;
+                constexpr bool PREFETCH_RES = sizeof(TIN) == 2 && !NORES;
                 bf16x4 rr[PREFETCH_RES ? FM : 1][PREFETCH_RES ? FN : 1];
                 if constexpr (PREFETCH_RES) {
                     if (a.res) {
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                     const int pl = wm * WM + j * 16 + px;   // pixel inside the tile
                     if (pl / PM != pass) continue;
                     const long long m = m0 + pl;
-                    const char* rrow = (a.res && m < a.M) ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
+                    const char* rrow = (!NORES && a.res && m < a.M) ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
                     char* lrow = smem + (pl - pass * PM) * ROWB;
 #pragma unroll
                     for (int i = 0; i < FN; ++i) {
@@ -817,7 +826,7 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
                         float r[4] = {0.f, 0.f, 0.f, 0.f};
                         if constexpr (PREFETCH_RES) {
                             if (a.res) { r[0] = (float)rr[j][i][0]; r[1] = (float)rr[j][i][1]; r[2] = (float)rr[j][i][2]; r[3] = (float)rr[j][i][3]; }
-                        } else {
+                        } else if constexpr (!NORES) {
                             if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
                         }
                         finish4<MODE>(v, r, cst + cl, cst + BN + cl, cst + 2 * BN + cl, a);

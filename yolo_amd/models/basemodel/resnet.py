@@ -84,45 +84,48 @@ class ResNet(nn.Module):
     def __init__(self, layers, zero_init_residual=False):
         super().__init__()
         self.inplanes = 64
-        self.first_layer = nn.Sequential(nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False),
-                                         nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        stem = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.first_layer = nn.Sequential(stem, nn.BatchNorm2d(64), nn.ReLU(inplace=True))
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
-        self.layer1 = self.make_layer(BasicBlock, 64, layers[0], stride=1)
-        self.layer2 = self.make_layer(BasicBlock, 128, layers[1], stride=2)
-        self.layer3 = self.make_layer(BasicBlock, 256, layers[2], stride=2)
-        self.layer4 = self.make_layer(BasicBlock, 512, layers[3], stride=2)
+        for k, (width, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2))):
+            setattr(self, f"layer{k + 1}", self.make_layer(BasicBlock, width, layers[k], stride=stride))
+        self._reset_parameters(zero_init_residual)
+
+    def _reset_parameters(self, zero_init_residual):
+        """He-normal (fan-out) convolutions, unit BatchNorms; optionally a zero gain on each block's last BatchNorm so
+        that a fresh block starts as the identity (reference :115-130)."""
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
             elif isinstance(m, nn.BatchNorm2d):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
         if zero_init_residual:
             for m in self.modules():
-                if isinstance(m, Bottleneck):
-                    nn.init.constant_(m.bn3.weight, 0)
-                elif isinstance(m, BasicBlock):
-                    nn.init.constant_(m.bn2.weight, 0)
+                last = m.bn3 if isinstance(m, Bottleneck) else m.bn2 if isinstance(m, BasicBlock) else None
+                if last is not None:
+                    nn.init.zeros_(last.weight)
 
     def make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
-                                       nn.BatchNorm2d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
-        return nn.Sequential(*layers)
+        """One stage: the first block carries the stride (and a 1x1 + BatchNorm projection when the shape changes),
+        the rest keep it (reference :132-146)."""
+        width = planes * block.expansion
+        project = None
+        if stride != 1 or self.inplanes != width:
+            project = nn.Sequential(conv1x1(self.inplanes, width, stride), nn.BatchNorm2d(width))
+        chain = [block(self.inplanes, planes, stride, project)] + [block(width, planes) for _ in range(blocks - 1)]
+        self.inplanes = width
+        return nn.Sequential(*chain)
+
+    def _stages(self, run, x):
+        y2 = run(self.layer2, run(self.layer1, x))
+        y3 = run(self.layer3, y2)
+        return y2, y3, run(self.layer4, y3)
 
     def forward(self, x):
-        y1 = self.layer1(self.first_layer(x))
-        y2 = self.layer2(y1)
-        y3 = self.layer3(y2)
-        return y2, y3, self.layer4(y3)
+        return self._stages(lambda m, t: m(t), self.first_layer(x))
 
     def lower(self, g, x):
         from ...engine import lower_any
         y = g.conv(x, self.first_layer[0], self.first_layer[1], **_RELU)
-        y2 = lower_any(g, self.layer2, lower_any(g, self.layer1, y))
-        y3 = lower_any(g, self.layer3, y2)
-        return y2, y3, lower_any(g, self.layer4, y3)
+        return self._stages(lambda m, t: lower_any(g, m, t), y)

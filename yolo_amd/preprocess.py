@@ -92,8 +92,8 @@ def preprocess_u8(images, placements, out_hw, device=None, pad_value=(114, 114, 
     with torch.cuda.device(device):
         _ffi.check(lib.ydet_preprocess_u8(dtable.data_ptr(), C.byref(d), out.data_ptr(), _ffi.current_stream()),
                    "ydet_preprocess_u8")
-        for t in held + [dtable]:     # the sources must outlive the asynchronous launch
-            t.record_stream(torch.cuda.current_stream())
+    # `held` / `dtable` were allocated (or already lived) on the launch stream: the caching allocator reuses their memory
+    # in stream order, so the asynchronous kernel is done with them before anything else can get it
     return out
 
 
