@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 8
+#define YDET_ABI_VERSION 9
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -130,6 +130,13 @@ int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
  * workgroups write their outputs).  Same bf16 intermediate and accumulation order as the two stages run through
  * ydet_conv2d_nhwc. */
 int ydet_bottleneck_fused(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, void* stream);
+
+/* The tail of a C3 block as ONE kernel: its last 32-channel bottleneck (cv1, cv2 as for ydet_bottleneck_fused; cv2->y is
+ * not used) and `self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), dim=1))` (yolov5_official/modules.py:252-253)
+ * with cv3 a 1x1 convolution 64 -> 64 sharing the activation.  cv3->x is the slice holding the OTHER half of the concat
+ * (the 32 channels of C3.cv2(x)); its weights are packed for 64 input channels, bottleneck output first; cv3->y is the
+ * block's output slice.  Neither the bottleneck's output nor the concat is written.  bf16 only. */
+int ydet_c3_tail_fused(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, const ydet_conv_desc* cv3, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pooling / resampling / layout operators on NHWC slices.
@@ -340,7 +347,8 @@ typedef enum {
     YDET_OP_NHWC2NCHW = 8,     /* iarg3 = destination dtype */
     YDET_OP_FOCUS_CONV = 9,    /* conv: as ydet_focus_conv3x3_nchw; iarg3 = image dtype */
     YDET_OP_HEAD_DECODE = 10,  /* conv + head: as ydet_head_conv_decode */
-    YDET_OP_BOTTLENECK = 11 /* conv + conv2: as ydet_bottleneck_fused */
+    YDET_OP_BOTTLENECK = 11,/* conv + conv2: as ydet_bottleneck_fused */
+    YDET_OP_C3_TAIL = 12    /* conv + conv2 + conv3: as ydet_c3_tail_fused */
 } ydet_op_kind;
 
 typedef struct {
@@ -349,7 +357,8 @@ typedef struct {
     ydet_conv_desc conv;   /* YDET_OP_CONV, YDET_OP_FOCUS_CONV, YDET_OP_HEAD_DECODE */
     ydet_slice_desc slice; /* pooling / resampling / layout ops */
     ydet_head_desc head;   /* YDET_OP_HEAD_DECODE */
-    ydet_conv_desc conv2;  /* YDET_OP_BOTTLENECK: the 3x3 stage */
+    ydet_conv_desc conv2;  /* YDET_OP_BOTTLENECK, YDET_OP_C3_TAIL: the 3x3 stage */
+    ydet_conv_desc conv3;  /* YDET_OP_C3_TAIL: cv3 */
 } ydet_op;
 
 int ydet_run_ops(const ydet_op* ops /* host */, int n_ops, void* stream);

@@ -526,3 +526,28 @@ def test_v5s_uint8_images_equal_scaled_float_images():
         zf, xf = m(u8.float() / 255.0)
         assert torch.equal(z8, zf) and all(torch.equal(a, b) for a, b in zip(x8, xf)), compute
     engine.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_c3_tail_fused_equals_separate_ops(n):
+    """First-stage C3 (64 -> 64, 32-channel bottlenecks): last bottleneck + concat + cv3 as one kernel gives bit for bit
+    what the bottleneck kernel followed by the cv3 convolution gives, and matches torch within the bf16 bar."""
+    from yolo_amd.yolov5_official.modules import C3
+    blk = C3(64, 64, n=n)
+    init_deterministic(blk, seed=3)
+    blk = blk.eval()
+    x = torch.randn(2, 64, 21, 37, generator=_gen(5, f"c3tail{n}")).bfloat16().float()
+    outs = {}
+    for fused in (True, False):
+        gr = engine.Graph(DEV, "bf16")
+        if not fused:
+            gr.c3_tail = lambda *a, **k: None
+        blk_dev = blk.to(DEV)
+        gr.to_nchw(blk_dev.lower(gr, gr.input_nchw(*x.shape)), "y")
+        kinds = [k for k, _ in gr.ops]
+        assert kinds.count("c3tail") == (1 if fused else 0)
+        outs[fused] = gr.finalize().run(x.to(DEV))["y"]
+    assert torch.equal(outs[True], outs[False])
+    with torch.no_grad():
+        ref = blk.cpu().float()(x)
+    assert rel_err(outs[True].float().cpu().numpy(), ref.numpy()) < 2e-2

@@ -13,9 +13,9 @@ F32, BF16, U8 = 0, 1, 2   # U8: output dtype of ydet_preprocess_u8 only
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
- OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK) = range(12)
+ OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK, OP_C3_TAIL) = range(13)
 MAX_ANCHORS = 8
-ABI_VERSION = 8   # YDET_ABI_VERSION of include/ydet.h these structs were written against
+ABI_VERSION = 9   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -82,7 +82,7 @@ class PreprocDesc(C.Structure):
 class Op(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("iarg", C.c_int32), ("iarg2", C.c_int32), ("iarg3", C.c_int32),
-        ("conv", ConvDesc), ("slice", SliceDesc), ("head", HeadDesc), ("conv2", ConvDesc),
+        ("conv", ConvDesc), ("slice", SliceDesc), ("head", HeadDesc), ("conv2", ConvDesc), ("conv3", ConvDesc),
     ]
 
 
@@ -104,6 +104,7 @@ SYMBOLS = {
     "ydet_process_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "ydet_bottleneck_fused": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
+    "ydet_c3_tail_fused": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
     "ydet_decode_v5": (C.c_int, [C.POINTER(V5Level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "ydet_decode_v2v3": (C.c_int, [C.POINTER(FALevel), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -30,6 +30,12 @@ struct BneckArgs {
     float slope;
     int add;
     int tiles_x, tiles_per_img, n_tiles;
+    // C3 tail (32-channel kernel only): cv3 = 1x1 over [this bottleneck's output | z], 64 -> 64, written to y3
+    const char* w3;
+    const float* b3;
+    const char* z;
+    char* y3;
+    int z_ld, z_coff, y3_ld, y3_coff, kp3;
 };
 
 __device__ __forceinline__ float act_fn(float v, bool silu, float slope) {
@@ -37,7 +43,12 @@ __device__ __forceinline__ float act_fn(float v, bool silu, float slope) {
     return v > 0.f ? v : v * slope;
 }
 
-__global__ __launch_bounds__(256) void bottleneck_c32_kernel(const BneckArgs a) {
+// TAIL: the block is the last bottleneck of a C3 whose concat [bottleneck output | cv2(x)] feeds cv3 (a 1x1, 64 -> 64,
+// yolov5_official/modules.py:252-253).  The eight channels a lane has just finished for its pixel ARE the B fragment of
+// cv3's first K step, the other half's eight channels (one 16-byte load) the second: cv3 runs on the tile in registers
+// and neither the bottleneck's output nor the concat is written.
+template <bool TAIL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_c32_kernel(const BneckArgs a) {
     __shared__ __attribute__((aligned(16))) char xs[PATCH_BYTES];   // input patch, bf16 [pixel][32] at PITCH
     __shared__ __attribute__((aligned(16))) char ts[PATCH_BYTES];   // act(conv1x1) of the patch, zero outside the image
 
@@ -64,6 +75,21 @@ __global__ __launch_bounds__(256) void bottleneck_c32_kernel(const BneckArgs a) 
         for (int e = 0; e < 4; ++e) {
             b1v[i][e] = a.b1[q * 8 + i * 4 + e];
             b2v[i][e] = a.b2[q * 8 + i * 4 + e];
+        }
+    }
+
+    // cv3: fragments (2h, 2h+1) cover output channels 32h .. 32h+31 with the same row permutation, K step s = half s
+    bf16x8 w3f[TAIL ? 4 : 1][2];
+    float b3v[TAIL ? 4 : 1][4];
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = (i >> 1) * 32 + (arow >> 2) * 8 + (i & 1) * 4 + (arow & 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                w3f[i][h] = *reinterpret_cast<const bf16x8*>(a.w3 + ((size_t)co * a.kp3 + h * 32 + q * 8) * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b3v[i][e] = a.b3[(i >> 1) * 32 + q * 8 + (i & 1) * 4 + e];
         }
     }
 
@@ -120,9 +146,17 @@ __global__ __launch_bounds__(256) void bottleneck_c32_kernel(const BneckArgs a) 
         }
         __syncthreads();
         // ---- 3x3 over ts, + residual, -> y: a wave owns two output rows, i.e. four groups of 16 pixels ----------
-#pragma unroll
+        // (with the cv3 tail the groups run one after the other: unrolled they need more than the 256 registers that
+        // two workgroups per CU leave a lane)
+#pragma unroll(TAIL ? 1 : 4)
         for (int gi = 0; gi < 4; ++gi) {
             const int row = wave * 2 + (gi >> 1), col0 = (gi & 1) * 16;
+            const int oy = oy0 + row, ox = ox0 + col0 + px;
+            const bool inside = oy < a.H && ox < a.W;
+            bf16x8 zb = {};
+            if constexpr (TAIL) {   // the other half of cv3's input, requested before the tap walk
+                if (inside) zb = *reinterpret_cast<const bf16x8*>(a.z + ((((size_t)n * a.H + oy) * a.W + ox) * a.z_ld + a.z_coff + q * 8) * 2);
+            }
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -131,7 +165,6 @@ __global__ __launch_bounds__(256) void bottleneck_c32_kernel(const BneckArgs a) 
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t][0], tb, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t][1], tb, acc1, 0, 0, 0);
             }
-            const int oy = oy0 + row, ox = ox0 + col0 + px;
             bf16x8 res;
             if (a.add) res = *reinterpret_cast<const bf16x8*>(xs + ((row + 1) * PW + col0 + 1 + px) * PITCH + q * 16);
             bf16x8 o;
@@ -142,8 +175,28 @@ __global__ __launch_bounds__(256) void bottleneck_c32_kernel(const BneckArgs a) 
                 o[e] = (__bf16)v0;
                 o[4 + e] = (__bf16)v1;
             }
-            if (oy < a.H && ox < a.W)
-                *reinterpret_cast<bf16x8*>(a.y + ((((size_t)n * a.H + oy) * a.W + ox) * a.y_ld + a.y_coff + q * 8) * 2) = o;
+            if constexpr (!TAIL) {
+                if (inside)
+                    *reinterpret_cast<bf16x8*>(a.y + ((((size_t)n * a.H + oy) * a.W + ox) * a.y_ld + a.y_coff + q * 8) * 2) = o;
+            } else {
+                f32x4 acc3[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc3[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[i][0], o, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acc3[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[i][1], zb, acc3[i], 0, 0, 0);
+                }
+                char* yrow = a.y3 + ((((size_t)n * a.H + oy) * a.W + ox) * a.y3_ld + a.y3_coff) * 2;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8 o3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o3[e] = (__bf16)act_fn(acc3[2 * h][e] + b3v[2 * h][e], silu, slope);
+                        o3[4 + e] = (__bf16)act_fn(acc3[2 * h + 1][e] + b3v[2 * h + 1][e], silu, slope);
+                    }
+                    if (inside) *reinterpret_cast<bf16x8*>(yrow + (h * 32 + q * 8) * 2) = o3;
+                }
+            }
         }
         __syncthreads();   // xs / ts are rewritten by the next tile
     }
@@ -307,10 +360,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
-int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, hipStream_t stream) {
+int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, const ydet_conv_desc* c3, hipStream_t stream) {
     using namespace ydet;
     YDET_CHECK_ARG(c1 && c2, "bottleneck_fused: null descriptor");
-    YDET_CHECK_ARG(c1->x && c1->w && c1->bias && c2->w && c2->bias && c2->y, "bottleneck_fused: null x/w/bias/y pointer");
+    YDET_CHECK_ARG(c1->x && c1->w && c1->bias && c2->w && c2->bias && (c2->y || c3), "bottleneck_fused: null x/w/bias/y pointer");
     YDET_CHECK_ARG(c1->in_dtype == YDET_BF16 && c1->out_dtype == YDET_BF16 && c2->in_dtype == YDET_BF16 &&
                        c2->out_dtype == YDET_BF16, "bottleneck_fused: bf16 only");
     const int C = c1->Cin;
@@ -327,16 +380,30 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, h
     YDET_CHECK_ARG(c1->res == nullptr && c1->post_scale == nullptr && c2->post_scale == nullptr && c1->y2 == nullptr &&
                        c2->y2 == nullptr, "bottleneck_fused: no residual on the first stage, no second stage or destination");
     YDET_CHECK_ARG(c1->x_ld % 8 == 0 && c1->x_coff % 8 == 0 && c1->x_coff >= 0 && c1->x_coff + C <= c1->x_ld &&
-                       c2->y_ld % 8 == 0 && c2->y_coff % 8 == 0 && c2->y_coff >= 0 && c2->y_coff + C <= c2->y_ld,
+                       (c3 || (c2->y_ld % 8 == 0 && c2->y_coff % 8 == 0 && c2->y_coff >= 0 && c2->y_coff + C <= c2->y_ld)),
                    "bottleneck_fused: channel slices must be 8-aligned and inside their rows");
-    YDET_CHECK_ARG(((uintptr_t)c1->x & 15) == 0 && ((uintptr_t)c2->y & 15) == 0 && ((uintptr_t)c1->w & 15) == 0 &&
+    YDET_CHECK_ARG(((uintptr_t)c1->x & 15) == 0 && (c3 || ((uintptr_t)c2->y & 15) == 0) && ((uintptr_t)c1->w & 15) == 0 &&
                        ((uintptr_t)c2->w & 15) == 0, "bottleneck_fused: pointers must be 16-byte aligned");
+    if (c3) {
+        YDET_CHECK_ARG(C == 32 && c3->x && c3->w && c3->bias && c3->y, "c3_tail_fused: 32-channel bottleneck, non-null x/w/bias/y of cv3");
+        YDET_CHECK_ARG(c3->KH == 1 && c3->KW == 1 && c3->stride == 1 && c3->pad == 0 && c3->Cin == 64 && c3->Cout == 64 &&
+                           c3->kp == 64 && c3->cout_pad >= 64 && c3->N == c1->N && c3->H == c1->H && c3->W == c1->W,
+                       "c3_tail_fused: cv3 must be a 1x1 convolution 64 -> 64 over the bottleneck's map");
+        YDET_CHECK_ARG(c3->in_dtype == YDET_BF16 && c3->out_dtype == YDET_BF16 && c3->act == c1->act && c3->slope == c1->slope &&
+                           c3->res == nullptr && c3->post_scale == nullptr && c3->y2 == nullptr && c3->x_up == nullptr,
+                       "c3_tail_fused: cv3 shares the activation, bf16, no residual / second stage / destination / source");
+        YDET_CHECK_ARG(c3->x_ld % 8 == 0 && c3->x_coff % 8 == 0 && c3->x_coff >= 0 && c3->x_coff + 32 <= c3->x_ld &&
+                           c3->y_ld % 8 == 0 && c3->y_coff % 8 == 0 && c3->y_coff >= 0 && c3->y_coff + 64 <= c3->y_ld &&
+                           ((uintptr_t)c3->x & 15) == 0 && ((uintptr_t)c3->y & 15) == 0 && ((uintptr_t)c3->w & 15) == 0,
+                       "c3_tail_fused: cv3 slices (x: the 32 channels of the other half) must be 8-aligned, pointers 16-byte aligned");
+        YDET_CHECK_ARG(c3->y != c1->x, "c3_tail_fused: the output must not be the bottleneck's input buffer");
+    }
     const bool add = c2->res != nullptr;
     if (add)
         YDET_CHECK_ARG(c2->res == c1->x && c2->res_ld == c1->x_ld && c2->res_coff == c1->x_coff &&
                            c2->res_mode == YDET_RES_AFTER_ACT, "bottleneck_fused: the residual is the block's own input, added last");
     // the halo of a tile is read while other workgroups write their outputs: in-place operation would race
-    const bool same_buf = c2->y == c1->x && c2->y_ld == c1->x_ld;
+    const bool same_buf = !c3 && c2->y == c1->x && c2->y_ld == c1->x_ld;
     YDET_CHECK_ARG(!same_buf || c2->y_coff + C <= c1->x_coff || c1->x_coff + C <= c2->y_coff,
                    "bottleneck_fused: output slice overlaps the input slice");
     BneckArgs a;
@@ -346,6 +413,11 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, h
     a.x_ld = c1->x_ld; a.x_coff = c1->x_coff; a.y_ld = c2->y_ld; a.y_coff = c2->y_coff;
     a.kp1 = c1->kp; a.kp2 = c2->kp;
     a.act = c1->act; a.slope = c1->slope; a.add = add ? 1 : 0;
+    a.w3 = nullptr; a.b3 = nullptr; a.z = nullptr; a.y3 = nullptr; a.z_ld = a.z_coff = a.y3_ld = a.y3_coff = a.kp3 = 0;
+    if (c3) {
+        a.w3 = (const char*)c3->w; a.b3 = c3->bias; a.z = (const char*)c3->x; a.y3 = (char*)c3->y;
+        a.z_ld = c3->x_ld; a.z_coff = c3->x_coff; a.y3_ld = c3->y_ld; a.y3_coff = c3->y_coff; a.kp3 = c3->kp;
+    }
     const int tw = C == 32 ? TW : c64::TW, th = C == 32 ? TH : c64::TH;
     a.tiles_x = (a.W + tw - 1) / tw;
     const long long tiles_y = (a.H + th - 1) / th;
@@ -359,7 +431,8 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, h
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     const long long grid = n_tiles < 2LL * cus ? n_tiles : 2LL * cus;
-    if (C == 32) hipLaunchKernelGGL(bottleneck_c32_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    if (C == 32 && c3) hipLaunchKernelGGL(bottleneck_c32_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else if (C == 32) hipLaunchKernelGGL(bottleneck_c32_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(bottleneck_c64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
     YDET_CHECK_LAUNCH("bottleneck kernel");
     return YDET_OK;
@@ -367,5 +440,11 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, h
 
 extern "C" int ydet_bottleneck_fused(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, void* stream) {
     ydet::clear_error();
-    return ydet_launch_bottleneck(cv1, cv2, ydet::as_stream(stream));
+    return ydet_launch_bottleneck(cv1, cv2, nullptr, ydet::as_stream(stream));
+}
+
+extern "C" int ydet_c3_tail_fused(const ydet_conv_desc* cv1, const ydet_conv_desc* cv2, const ydet_conv_desc* cv3, void* stream) {
+    ydet::clear_error();
+    if (!cv3) return ydet::fail(YDET_ERR_ARG, "c3_tail_fused: null cv3 descriptor");
+    return ydet_launch_bottleneck(cv1, cv2, cv3, ydet::as_stream(stream));
 }

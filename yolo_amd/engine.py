@@ -269,6 +269,32 @@ class Graph:
                      res_mode=_ffi.RES_AFTER_ACT if add else _ffi.RES_NONE))))
         return out
 
+    def c3_tail(self, x, cv1, cv2, other, cv3, act=_ffi.ACT_NONE, slope=0.0, add=True):
+        """cv3(cat(bottleneck(x), other)) as ONE kernel for a 32-channel bottleneck (cv1 1x1, cv2 3x3, optional shortcut)
+        and cv3 = (1x1 conv 64 -> 64, bn) with the same activation: neither the bottleneck's output nor the concat is
+        written.  Returns None when the shapes do not qualify (the caller then lowers the pieces separately)."""
+        (c1, bn1), (c2, bn2), (c3, bn3) = cv1, cv2, cv3
+        geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups)
+        ok = (self.dt == _ffi.BF16 and x.C == 32 and other.C == 32 and x.dtype == _ffi.BF16 and other.dtype == _ffi.BF16
+              and c1.out_channels == 32 and c2.out_channels == 32 and geom(c1) == (1, 1, 0, 1) and geom(c2) == (3, 1, 1, 1)
+              and geom(c3) == (1, 1, 0, 1) and c3.in_channels == 64 and c3.out_channels == 64
+              and (other.N, other.H, other.W) == (x.N, x.H, x.W))
+        if not ok:
+            return None
+        pc1 = pack_conv(c1, bn1, None, cin_phys=32, dtype=self.dt, device=self.device)
+        pc2 = pack_conv(c2, bn2, None, cin_phys=32, dtype=self.dt, device=self.device)
+        pc3 = pack_conv(c3, bn3, None, cin_phys=64, dtype=self.dt, device=self.device)
+        self.keep += [pc1, pc2, pc3]
+        out = self.new(x.N, x.H, x.W, 64)
+        common = dict(act=act, slope=float(slope), post=None, res_mode=_ffi.RES_NONE, res=None)
+        self.ops.append(("c3tail", dict(
+            x=x, y=out, other=other, add=bool(add), pc=pc1, pc2=pc2, pc3=pc3,
+            cv1=dict(common, x=x, y=out, pc=pc1, stride=1, pad=0),
+            cv2=dict(common, x=x, y=out, pc=pc2, stride=1, pad=1, res=x if add else None,
+                     res_mode=_ffi.RES_AFTER_ACT if add else _ffi.RES_NONE),
+            cv3=dict(common, x=other, y=out, pc=pc3, stride=1, pad=0))))
+        return out
+
     def head_decode(self, x, conv, z, row_max, level_off, na, no, stride, anchors, transposed):
         """1x1 prediction conv of one Detect level with the decode in its epilogue.  z / row_max: external storages
         [N,1,rows,no] / [N,1,rows,1] shared by the levels; returns the raw fp32 head map (external, 256-padded)."""
@@ -379,7 +405,7 @@ class Graph:
             for k2, a2 in self.ops:
                 if a2 is up_rec:
                     continue
-                for t in (reads(a2) + ([a2["cv1"]["x"]] if k2 == "bottleneck" else [])):
+                for t in (reads(a2) + ([a2["cv1"]["x"]] if k2 == "bottleneck" else []) + ([a2["other"]] if k2 == "c3tail" else [])):
                     root, off = t.resolve()
                     if root is uroot and off < uoff + C_up and uoff < off + t.C:
                         fits = (k2 == "conv" and t is a2["x"] and off == uoff and a2.get("up_cand") is not None
@@ -450,6 +476,15 @@ class Plan:
             self._fill_conv(op, i, a["cv1"], arena, record)
             self._fill_conv(op, i, a["cv2"], arena, record, d=op.conv2)
             op.kind = _ffi.OP_BOTTLENECK
+        elif kind == "c3tail":
+            assert not any(a[k].resolve()[0].external for k in ("x", "y", "other"))
+            self._fill_conv(op, i, a["cv1"], arena, record)
+            self._fill_conv(op, i, a["cv2"], arena, record, d=op.conv2)
+            self._fill_conv(op, i, a["cv3"], arena, record, d=op.conv3)
+            op.conv.Cout = op.conv2.Cin = op.conv2.Cout = 32           # (their y fields point at the 64-wide output)
+            op.conv3.Cin, op.conv3.x_ld, op.conv3.x_coff = 64, a["other"].resolve()[0].ld, a["other"].resolve()[1]
+            op.conv2.y = 0
+            op.kind = _ffi.OP_C3_TAIL
         elif kind == "head_decode":
             self._fill_conv(op, i, a, arena, record)
             op.kind = _ffi.OP_HEAD_DECODE
@@ -712,6 +747,11 @@ def _op_info(kind, a):
                     flops=flops,
                     bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
+    if kind == "c3tail":
+        x, y = a["x"], a["y"]
+        px = y.N * y.H * y.W
+        return dict(kind="conv", label="conv_c3_tail_c32", flops=2.0 * px * (32 * 32 * 10 + 64 * 64),
+                    bytes=px * (32 + 32 + 64) * 2 + (10 * 32 * 32 + 64 * 64) * 2, shape=(x.N, x.H, x.W, 64, 64, 3, 1))
     if kind == "bottleneck":
         x, y = a["x"], a["y"]
         px = y.N * y.H * y.W

@@ -145,8 +145,17 @@ class C3(nn.Module):
                 # conv sends cv1(x) to a buffer of its own and cv2(x) to what becomes the second half of the concat
                 # buffer; the last bottleneck's output becomes the first half
                 _, (y, y2) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1, separate=True)
-                for b in self.m:
+                for b in list(self.m)[:-1]:
                     y = b.lower(g, y)
+                last = list(self.m)[-1]
+                la = (activation_code(last.cv1.act), activation_code(last.cv2.act), activation_code(self.cv3.act))
+                if c_ == 32 and la[0] == la[1] == la[2] == a1 and a1[0] != _ffi.ACT_NONE and hasattr(self.cv3, "bn"):
+                    # the last bottleneck, the concat and cv3 as one kernel (32-channel stage only)
+                    out = g.c3_tail(y, (last.cv1.conv, last.cv1.bn), (last.cv2.conv, last.cv2.bn), y2,
+                                    (self.cv3.conv, self.cv3.bn), *a1, add=last.add)
+                    if out is not None:
+                        return out
+                y = last.lower(g, y)
                 return self.cv3.lower(g, g.cat([y, y2]))
             cat, (y, _) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1)
             for b in self.m:
