@@ -38,15 +38,16 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_match_header_layout():
     """sizeof() of the ctypes mirrors against a C compile of the header (catches field drift)."""
     from yolo_amd import _ffi
-    src = '#include <stdio.h>\n#include "ydet.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(ydet_conv_desc),' \
-          'sizeof(ydet_slice_desc), sizeof(ydet_v5_level), sizeof(ydet_fa_level), sizeof(ydet_op));return 0;}'
+    src = '#include <stdio.h>\n#include "ydet.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ydet_conv_desc),' \
+          'sizeof(ydet_slice_desc), sizeof(ydet_v5_level), sizeof(ydet_fa_level), sizeof(ydet_op), sizeof(ydet_head_desc),' \
+          'sizeof(ydet_u8_image), sizeof(ydet_preproc_desc));return 0;}'
     exe = os.path.join(ROOT, "build", "abi_sizes")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     sizes = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
     import ctypes as C
     assert sizes == [C.sizeof(_ffi.ConvDesc), C.sizeof(_ffi.SliceDesc), C.sizeof(_ffi.V5Level), C.sizeof(_ffi.FALevel),
-                     C.sizeof(_ffi.Op)]
+                     C.sizeof(_ffi.Op), C.sizeof(_ffi.HeadDesc), C.sizeof(_ffi.U8Image), C.sizeof(_ffi.PreprocDesc)]
 
 
 def test_no_gpu_means_loud_failure():
