@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 9
+#define YDET_ABI_VERSION 10
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -107,6 +107,16 @@ typedef struct {
      * H, W even; x_up_C and Cin multiples of the K step (32 bf16 / 16 f32); Cout > 32.  NULL = one source. */
     const void* x_up;
     int32_t x_up_ld, x_up_coff, x_up_C;
+    /* Optional 1x1 follower: a second convolution (1x1 / stride 1, pw_cout output channels, weights pw_w packed like w
+     * for 64 input channels, pw_kp = 64, bias pw_bias) applied to the finished values of this one while they are still
+     * in registers:  y = act(pw(act(conv(x) + bias)) + pw_bias), one activation for both.  The output slices (y, y2,
+     * y_split) then hold the follower's channels; the 64-channel map in between is never written.  This is
+     * `Conv(32, 64, 3, 2)` followed by the C3's cv1 | cv2 pair (yolov5s.yaml backbone rows 1-2,
+     * yolov5_official/modules.py:252).  Needs bf16, Cout == 64, 32 < pw_cout <= 64, Cin a multiple of 32; excludes res,
+     * post_*, cout_store and x_up.  NULL = no follower. */
+    const void* pw_w;
+    const float* pw_bias;
+    int32_t pw_cout, pw_kp;
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 

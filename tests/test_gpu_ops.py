@@ -727,3 +727,37 @@ def test_upsample_is_kept_when_another_op_reads_it():
     assert [k for k, _ in g.ops].count("upsample") == 1
     cat = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), b], 1)
     assert rel_err(out["y"].cpu(), conv(cat)) < 1e-3 and rel_err(out["y3"].cpu(), conv3(cat)) < 1e-3
+
+
+# ---- a 1x1 convolution run on the tile of the 64-channel convolution in front of it -------------------------------
+@pytest.mark.parametrize("geom", [(3, 2, 1, 32, 64), (3, 1, 1, 64, 48), (1, 1, 0, 96, 64)])
+def test_conv_with_pointwise_follower(geom):
+    """conv (k, s, p, Cin -> 64) + SiLU followed by a 1x1 conv (64 -> Cout2) + SiLU as one launch: equal to the two
+    launches up to the rounding of a different summation order inside a K step, and to torch within the bf16 bar."""
+    k, s, p, cin, cout2 = geom
+    gen = _gen(13, f"pw{geom}")
+    x = torch.randn(2, cin, 22, 26, generator=gen).bfloat16().float()
+    c1 = nn.Conv2d(cin, 64, k, s, p).requires_grad_(False)
+    c2 = nn.Conv2d(64, cout2, 1).requires_grad_(False)
+    c1.weight.copy_(torch.randn(c1.weight.shape, generator=gen) * (2.0 / (cin * k * k)) ** 0.5)
+    c2.weight.copy_(torch.randn(c2.weight.shape, generator=gen) * 0.15)
+
+    def build(gr, ins):
+        t = gr.conv(ins[0], c1, act=_ffi.ACT_SILU)
+        gr.to_nchw(gr.conv(t, c2, act=_ffi.ACT_SILU), "y")
+
+    outs = {}
+    for fused in (True, False):
+        engine.set_follower_fusion(fused)
+        try:
+            g = engine.Graph(DEV, "bf16")
+            build(g, [g.input_nchw(*x.shape)])
+            plan = g.finalize()
+            assert [k_ for k_, _ in g.ops].count("conv") == (1 if fused else 2)
+            outs[fused] = plan.run(x.to(DEV))["y"].float().cpu()
+        finally:
+            engine.set_follower_fusion(True)
+    assert rel_err(outs[True].numpy(), outs[False].numpy()) < 1e-2      # bf16 outputs: a few values differ by one ulp
+    assert (outs[True] != outs[False]).float().mean() < 0.02
+    ref = F.silu(c2(F.silu(c1(x))))
+    assert rel_err(outs[True].numpy(), ref.numpy()) < 2e-2

@@ -142,14 +142,15 @@ def test_planner_v5s_on_cpu():
     # 62 convolutions: 8 C3 (cv1, cv2) pairs fused, the first one fused with the Focus slicing and the NCHW edge, the
     # 32- and 64-channel bottlenecks (1x1 + 3x3: one in the first C3, three in the second, one in the last neck C3 at
     # 80 x 80) one kernel each, the three prediction convs decode in place
-    assert kinds[0] == "focus_conv" and kinds.count("conv") == 39 and kinds.count("bottleneck") == 4 and kinds.count("c3tail") == 1
+    assert kinds[0] == "focus_conv" and kinds.count("conv") == 38 and kinds.count("bottleneck") == 4 and kinds.count("c3tail") == 1
     assert kinds.count("head_decode") == 3 and "copy" not in kinds
     assert kinds.count("spp") == 1 and kinds.count("upsample") == 0      # both upsamples ride in the 1x1 convs behind them
     tail = [op for op in plan.ops if op.kind == 12][0]        # first C3: bottleneck + concat + cv3 in one kernel
     assert (tail.conv.x_ld, tail.conv.x_coff, tail.conv2.res_ld, tail.conv3.x_ld, tail.conv3.x_coff, tail.conv3.Cin,
             tail.conv3.y_ld, tail.conv3.y_coff) == (32, 0, 32, 32, 0, 64, 64, 0)
-    sib = plan.ops[1 + 1]                                     # the C3's sibling conv: cv1 and cv2 each to a buffer of its own
-    assert (sib.conv.Cout, sib.conv.y_split, sib.conv.y_ld, sib.conv.y2_ld, sib.conv.y2_coff) == (64, 32, 32, 32, 0)
+    sib = plan.ops[1]                                         # Conv(32, 64, 3, 2) with the C3's sibling pair (cv1 | cv2) run on its
+    assert (sib.conv.KH, sib.conv.stride, sib.conv.Cin, sib.conv.Cout, sib.conv.pw_cout, sib.conv.pw_kp) == (3, 2, 32, 64, 64, 64)  # tile
+    assert (sib.conv.y_split, sib.conv.y_ld, sib.conv.y2_ld, sib.conv.y2_coff) == (32, 32, 32, 0) and sib.conv.pw_w
     bn = [op for op in plan.ops if op.kind == 11][2]          # second C3 (64 channels): its last bottleneck writes concat half 1
     assert (bn.conv.x_ld, bn.conv.x_coff, bn.conv2.y_ld, bn.conv2.y_coff, bn.conv2.res_ld) == (64, 0, 128, 0, 64)
     gflop = sum(i["flops"] for i in plan.op_info) / 2 / 1e9

@@ -61,6 +61,9 @@ struct ConvArgs {
     char* y2;         // second destination: output channels y_split.. go to y2 (slice y2_ld / y2_coff), or null
     int y2_ld, y2_coff;
     int y_split;      // INT_MAX without a second destination
+    const char* pw_w; // a 1x1 convolution run on the finished tile in registers (64-channel tile only): its weights
+    const float* pw_b1;   // [cout_pad][pw_kp]; pw_b1 = bias of the FIRST convolution (a.bias is then the second's), or null
+    int pw_kp;
     const char* x_up; // pointwise convs only: input channels [0, up_C) are read from this map of half the size at
     int up_ld, up_coff, up_C;   // (h/2, w/2) -- a nearest-neighbour 2x upsample that is never materialised; 0: none
 };
@@ -556,6 +559,23 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 
     const int fr_off = (lane & 15) * 64 + (((lane >> 4) ^ chunk_swz(lane >> 2)) << 4);
 
+    // weights of a 1x1 follower (see below): requested now, so that their latency runs under the K loop
+    constexpr bool PW_OK = WARPS_N == 1 && BN == 64 && !HEAD && sizeof(TIN) == 2;
+    bf16x4 pw_lo[PW_OK ? 4 : 1][2], pw_hi[PW_OK ? 4 : 1][2];
+    if constexpr (PW_OK) {
+        if (a.pw_w) {
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const char* wrow = a.pw_w + (size_t)(i2 * 16 + (lane & 15)) * a.pw_kp * 2;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    pw_lo[i2][s2] = *reinterpret_cast<const bf16x4*>(wrow + (32 * s2 + 4 * (lane >> 4)) * 2);
+                    pw_hi[i2][s2] = *reinterpret_cast<const bf16x4*>(wrow + (32 * s2 + 16 + 4 * (lane >> 4)) * 2);
+                }
+            }
+        }
+    }
+
     const int nk = a.kp / BK;
     YDET_STAMP(1);
     issue(0);
@@ -592,6 +612,46 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int j = 0; j < FM; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+    }
+
+    // ---- optional 1x1 follower on the tile in registers ------------------------------------------------------
+    // A wave of the 64-channel tile holds every channel of its pixels.  Finished (bias, activation, bf16) the values a
+    // lane holds for one pixel -- channels 16 i + 4 q .. + 3 of fragments i = 2 s, 2 s + 1 -- are taken as the eight
+    // k values of B fragment s; the A fragments of the second convolution are loaded with their columns in that same
+    // order (two 8-byte pieces per lane), so the second GEMM needs no LDS pass and the first map never leaves the chip.
+    if constexpr (WARPS_N == 1 && BN == 64 && !HEAD && sizeof(TIN) == 2) {
+        if (a.pw_w) {
+            const int q_ = lane >> 4;
+            const bool silu1 = a.act == YDET_ACT_SILU;
+            bf16x8 bfr[2][FM];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 b1 = *reinterpret_cast<const float4*>(a.pw_b1 + i * 16 + q_ * 4);
+                const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][e] + bb[e];
+                        x = silu1 ? x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f))
+                                  : (x > 0.f ? x : x * a.slope);
+                        bfr[i >> 1][j][(i & 1) * 4 + e] = (__bf16)x;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 a2 = {pw_lo[i2][s2][0], pw_lo[i2][s2][1], pw_lo[i2][s2][2], pw_lo[i2][s2][3],
+                                       pw_hi[i2][s2][0], pw_hi[i2][s2][1], pw_hi[i2][s2][2], pw_hi[i2][s2][3]};
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i2][j] = mma(a2, bfr[s2][j], acc[i2][j]);
+                }
+        }
     }
 
     // ---- epilogue -------------------------------------------------------------------------------------
@@ -912,6 +972,7 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
         return YDET_OK;
     }
     if (a.y2) return fail(YDET_ERR_ARG, "conv: a second destination needs Cin to be a multiple of %d and at least 64 output channels", BK);
+    if (a.pw_w) return fail(YDET_ERR_ARG, "conv: a 1x1 follower needs the LDS-DMA kernel");
     if (a.x_up) return fail(YDET_ERR_ARG, "conv: an upsampled source needs the LDS-DMA kernel (Cin a multiple of %d, more than 32 output channels)", BK);
     if constexpr (WARPS_N * WARPS_M != 4) {
         return fail(YDET_ERR_ARG, "conv: the %dx%d tile needs Cin to be a multiple of %d", BN, BM, BK);
@@ -989,13 +1050,23 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     YDET_CHECK_ARG(d->Cin % epc == 0 && d->x_ld % epc == 0 && d->x_coff % epc == 0,
                    "conv: Cin/x_ld/x_coff (%d,%d,%d) must be multiples of %d", d->Cin, d->x_ld, d->x_coff, epc);
     YDET_CHECK_ARG(d->x_coff >= 0 && d->x_coff + d->Cin <= d->x_ld, "conv: input slice exceeds x_ld");
-    const int y_ch = d->y2 ? d->y_split : d->Cout;   // channels that land in y
+    const int cout_eff = d->pw_w ? d->pw_cout : d->Cout;   // channels of the finished tile
+    if (d->pw_w) {
+        YDET_CHECK_ARG(d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16 && d->Cout == 64 && d->pw_cout > 32 && d->pw_cout <= 64 &&
+                           d->pw_kp == 64 && d->Cin % bk == 0 && d->KH * d->KW <= 32 && d->bias && d->pw_bias &&
+                           ((uintptr_t)d->pw_w & 15) == 0 && ((uintptr_t)d->pw_bias & 15) == 0,
+                       "conv: a 1x1 follower needs bf16, 64 channels out of the first convolution, 33..64 out of the second "
+                       "(weights packed for 64 inputs), Cin a multiple of %d and both biases", bk);
+        YDET_CHECK_ARG(d->res == nullptr && d->post_scale == nullptr && d->cout_store == 0 && d->x_up == nullptr,
+                       "conv: a 1x1 follower excludes a residual, a second epilogue stage, cout_store and an upsampled source");
+    }
+    const int y_ch = d->y2 ? d->y_split : cout_eff;   // channels that land in y
     YDET_CHECK_ARG(d->y_coff >= 0 && d->y_coff + y_ch <= d->y_ld, "conv: output slice exceeds y_ld");
     if (d->y2) {
         const int vec = d->out_dtype == YDET_BF16 ? 8 : 4;
-        YDET_CHECK_ARG(d->y_split > 0 && d->y_split < d->Cout && d->y_split % vec == 0 && d->Cout % vec == 0 &&
+        YDET_CHECK_ARG(d->y_split > 0 && d->y_split < cout_eff && d->y_split % vec == 0 && cout_eff % vec == 0 &&
                            d->y2_ld % vec == 0 && d->y2_coff % vec == 0 && d->y2_coff >= 0 &&
-                           d->y2_coff + d->Cout - d->y_split <= d->y2_ld && ((uintptr_t)d->y2 & 15) == 0,
+                           d->y2_coff + cout_eff - d->y_split <= d->y2_ld && ((uintptr_t)d->y2 & 15) == 0,
                        "conv: second destination (split %d of %d channels, ld %d, coff %d)", d->y_split, d->Cout, d->y2_ld, d->y2_coff);
         YDET_CHECK_ARG(d->cout_store == 0 && d->res == nullptr, "conv: a second destination excludes cout_store and a residual");
     }
@@ -1033,6 +1104,12 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     a.cout_store = d->cout_store > 0 ? d->cout_store : d->Cout;
     a.y2 = (char*)d->y2; a.y2_ld = d->y2_ld; a.y2_coff = d->y2_coff;
     a.y_split = d->y2 ? d->y_split : 0x7fffffff;
+    a.pw_w = nullptr; a.pw_b1 = nullptr; a.pw_kp = 0;
+    if (d->pw_w) {      // from here on the tile is the second convolution's: its channel count, its bias
+        a.pw_w = (const char*)d->pw_w; a.pw_b1 = d->bias; a.pw_kp = d->pw_kp;
+        a.bias = d->pw_bias; a.Cout = d->pw_cout; a.cout_store = d->pw_cout;
+        a.vec_store = (d->pw_cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0) ? 1 : 0;
+    }
     a.x_up = nullptr; a.up_ld = 0; a.up_coff = 0; a.up_C = 0;
     if (d->x_up) {
         YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H % 2 == 0 && d->W % 2 == 0,

@@ -420,6 +420,50 @@ class Graph:
             del self.ops[idx]
             self.ext_in = [i - 1 if i > idx else i for i in self.ext_in]
 
+    # ---- a 64-channel convolution followed by a 1x1 convolution: the second runs on the first one's tile --------------
+    def fuse_pointwise_followers(self):
+        """conv A (bf16, 64 output channels, LDS-DMA shapes, nothing else fused in) whose output is read by exactly one
+        op, a 1x1 / stride 1 conv B with 33..64 output channels and the same activation: B takes over A's input and
+        geometry (`pre`), A disappears, and the kernel runs B on A's finished tile in registers."""
+        if not _fuse_followers or self.dt != _ffi.BF16:
+            return
+
+        def inputs(k, a):
+            ts = [a[key] for key in ("x", "res", "other") if isinstance(a.get(key), T)]
+            if k in ("bottleneck", "c3tail"):
+                ts.append(a["cv1"]["x"])
+            if a.get("up") is not None:
+                ts.append(a["up"][0])
+            return ts
+
+        out_roots = [v.resolve()[0] for v in self.outputs.values() if isinstance(v, T)]
+        i = 0
+        while i < len(self.ops):
+            ka, A = self.ops[i]
+            i += 1
+            if ka != "conv" or any(A.get(k) is not None for k in ("res", "post", "y2", "up", "pre")):
+                continue
+            pa, xa, ya = A["pc"], A["x"], A["y"]
+            ra, oa = ya.resolve()
+            if not (pa.Cout == 64 and xa.C % 32 == 0 and pa.KH * pa.KW <= 32 and xa.dtype == _ffi.BF16 and ya.dtype == _ffi.BF16
+                    and not ra.external and ya.whole() and ra is ya.st and all(r is not ra for r in out_roots)):
+                continue
+            readers = [(k2, a2) for k2, a2 in self.ops if a2 is not A and any(t.resolve()[0] is ra for t in inputs(k2, a2))]
+            if len(readers) != 1 or readers[0][0] != "conv":
+                continue
+            B = readers[0][1]
+            pb = B["pc"]
+            if not (B["x"].resolve() == (ra, oa) and B["x"].C == 64 and (pb.KH, pb.KW, B["stride"], B["pad"]) == (1, 1, 1, 0)
+                    and 32 < pb.Cout <= 64 and pb.kp == 64 and B["y"].dtype == _ffi.BF16
+                    and all(B.get(k) is None for k in ("res", "post", "up", "pre"))
+                    and (B["act"], B["slope"]) == (A["act"], A["slope"])):
+                continue
+            B["pre"] = dict(pc=pa, x=xa, stride=A["stride"], pad=A["pad"])
+            idx = i - 1
+            del self.ops[idx]
+            self.ext_in = [j - 1 if j > idx else j for j in self.ext_in]
+            i = idx
+
     # ---- finalize ------------------------------------------------------------------------------
     def finalize(self, replicas=1):
         return Plan(self, replicas)
@@ -438,6 +482,7 @@ class Plan:
         self.g = g
         self.R = replicas
         g.fuse_upsamples()
+        g.fuse_pointwise_followers()
         n = len(g.ops)
         self.patch_in = list(g.ext_in)  # op indices whose source is a caller-supplied NCHW input
         self.patch_out = []       # (op index, field, storage) of external NHWC buffers
@@ -567,6 +612,17 @@ class Plan:
             r2, o2 = a["y2"].resolve()
             assert r2.dtype == ry.dtype and not r2.external
             d.y2, d.y2_ld, d.y2_coff, d.y_split = arena[r2].data_ptr(), r2.ld, o2, y.C
+        if a.get("pre") is not None:     # this record is the 1x1 follower: the launch is the convolution in front of it
+            pre = a["pre"]
+            p1, x1 = pre["pc"], pre["x"]
+            r1, o1 = x1.resolve()
+            d.x = self._ptr(r1, arena, i, "cx", record)
+            d.w, d.bias = p1.w.data_ptr(), p1.b.data_ptr()
+            d.H, d.W, d.Cin, d.x_ld, d.x_coff = x1.H, x1.W, x1.C, r1.ld, o1
+            d.Cout, d.KH, d.KW, d.stride, d.pad = p1.Cout, p1.KH, p1.KW, pre["stride"], pre["pad"]
+            d.kp, d.cout_pad, d.in_dtype = p1.kp, p1.cout_pad, r1.dtype
+            d.pw_w, d.pw_bias, d.pw_cout, d.pw_kp = pc.w.data_ptr(), pc.b.data_ptr(), pc.Cout, pc.kp
+            d.cout_store = 0
         if a.get("up") is not None:
             src, C_up = a["up"]
             ru, ou = src.resolve()
@@ -664,6 +720,15 @@ class Plan:
 
 _batch_split = 1
 _fuse_upsample = True
+_fuse_followers = True
+
+
+def set_follower_fusion(flag):
+    """Whether plans run a 1x1 convolution that is the only reader of a 64-channel convolution inside that
+    convolution's kernel (default on).  Off: two launches with the map in between written and read back."""
+    global _fuse_followers
+    _fuse_followers = bool(flag)
+
 
 
 def set_upsample_fusion(flag):
@@ -735,6 +800,15 @@ def _op_info(kind, a):
                   + y.N * y.H * y.W * pc.Cout * 4)
         return dict(kind="conv", label="conv_head_decode", flops=flops, bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, 1, 1))
+    if kind == "conv" and a.get("pre") is not None:
+        pre, y, pc = a["pre"], a["y"], a["pc"]
+        x, p1 = pre["x"], pre["pc"]
+        px = y.N * y.H * y.W
+        flops = 2.0 * px * (p1.Cout * p1.cin_real * p1.KH * p1.KW + pc.Cout * pc.cin_real)
+        nbytes = (x.N * x.H * x.W * x.C * esz(x) + px * pc.Cout * esz(y) + p1.Cout * p1.KH * p1.KW * x.C * esz(x)
+                  + pc.Cout * 64 * esz(x))
+        return dict(kind="conv", label=conv_kernel_label(x.C, p1.Cout, p1.KH, p1.KW, pre["pad"], x.dtype, y.dtype, M=px),
+                    flops=flops, bytes=nbytes, shape=(x.N, x.H, x.W, x.C, pc.Cout, p1.KH, pre["stride"]))
     if kind == "conv":
         x, y, pc = a["x"], a["y"], a["pc"]
         flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.cin_real * pc.KH * pc.KW
