@@ -54,7 +54,9 @@ struct Pair<uint8_t> {
 };
 
 template <typename TX, int FN>
-__global__ __launch_bounds__(256) void focus_conv3x3_kernel(const StemArgs a) {
+// the 32-channel form fits five workgroups per CU when held to 96 registers (90 used, no scratch); left to itself the
+// compiler takes 118 and four
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FN == 2 ? 5 : 2, FN == 2 ? 5 : 2))) void focus_conv3x3_kernel(const StemArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 F[FH * FW * 16];
     __shared__ __bf16 lut[std::is_same<TX, uint8_t>::value ? 256 : 1];
     if constexpr (std::is_same<TX, uint8_t>::value) lut[threadIdx.x] = (__bf16)((float)threadIdx.x / 255.0f);
