@@ -310,6 +310,8 @@ class Model(engine.AcceleratedModule):
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, x, augment=False):
         if augment:
+            if x.dtype == torch.uint8:     # the scaled / flipped copies are resampled in floating point
+                x = x.float() / 255.0
             return self.forward_augment(x)
         if x.is_cuda and not self.training:
             return self._forward_hip(x)
