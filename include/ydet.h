@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 10
+#define YDET_ABI_VERSION 11
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -130,6 +130,13 @@ int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
  * x_dtype YDET_U8: the image holds raw 0..255 pixel values and every value enters as bf16(float(v) / 255), the
  * `img.float() / 255` of yolov5_official/val.py:68-69 folded into the load (the fp32 image is never written). */
 int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
+
+/* The first layer of the Darknet-style trunks straight from the NCHW image: `Conv(3, C, k=3, p=1)` (utils/moduleUtils.py:8-24
+ * as used at models/basemodel/d19.py:22,88,133,175,221) including the NCHW -> NHWC edge conversion.  d->x is the image
+ * [N, 3, H, W] (x_dtype fp32 or bf16, contiguous), d->Cin = 3; 3x3 / stride 1 / pad 1; w / bias packed as for
+ * ydet_conv2d_nhwc for 4 input channels (the 3 image channels + a zero; kp = 64); d->y is the NHWC bf16 slice
+ * [N, H, W, Cout], Cout a multiple of 8, <= 64.  bf16 weights / output only; x_ld, x_coff, res, post_* unused. */
+int ydet_rgb_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
 
 /* A residual bottleneck with C = 32 or 64 channels throughout as ONE kernel: yolov5_official/modules.py:208-218,
  * `x + self.cv2(self.cv1(x))` with cv1 = Conv(C, C, 1, 1) and cv2 = Conv(C, C, 3, 1) (the bottlenecks of the first two
@@ -358,7 +365,8 @@ typedef enum {
     YDET_OP_FOCUS_CONV = 9,    /* conv: as ydet_focus_conv3x3_nchw; iarg3 = image dtype */
     YDET_OP_HEAD_DECODE = 10,  /* conv + head: as ydet_head_conv_decode */
     YDET_OP_BOTTLENECK = 11,/* conv + conv2: as ydet_bottleneck_fused */
-    YDET_OP_C3_TAIL = 12    /* conv + conv2 + conv3: as ydet_c3_tail_fused */
+    YDET_OP_C3_TAIL = 12,   /* conv + conv2 + conv3: as ydet_c3_tail_fused */
+    YDET_OP_RGB_CONV = 13   /* conv: as ydet_rgb_conv3x3_nchw; iarg3 = image dtype */
 } ydet_op_kind;
 
 typedef struct {

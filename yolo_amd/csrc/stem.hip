@@ -200,6 +200,142 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FN == 2 ? 5
     else finish(std::false_type{});
 }
 
+// ---- plain first layer: 3x3 / stride 1 / pad 1 over the 3 image channels ---------------------------------------------
+// (Darknet-19 / -53 / CSPDarknet / the tiny trunks: models/basemodel/d19.py:22,88,133,175,221.)  Same scheme as the Focus
+// kernel with image pixels in place of focus pixels: the 10 x 34 x 3 patch under an 8 x 32 output patch sits in LDS as
+// P[340][4] bf16 (3 channels + a zero, 8 bytes), K is tap-major with 4 channels per tap (k = tap*4 + c: 36 -> 64 = two
+// K steps), so a lane's 8 k-values are two taps = two 8-byte LDS reads.  As the generic convolution this layer ran on
+// channel-padded NHWC input behind a layout kernel and was the slowest launch of every one of those networks.
+template <typename TX, int FN>
+__global__ __launch_bounds__(256) void rgb_conv3x3_kernel(const StemArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 P[FH * FW * 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x, ty = bid / a.tiles_x, n = blockIdx.y;
+    const int i0 = ty * TH, j0 = tx * TW;
+    const int y0 = i0 - 1, x0 = j0 - 1;
+
+    bf16x8 wf[FN][2];
+    const int wrow = 8 * ((lane & 15) >> 2) + (lane & 3);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)(32 * (i >> 1) + 4 * (i & 1) + wrow) * 64 + s * 32 + (lane >> 4) * 8) * 2);
+
+    constexpr int NP = FH * FW;
+    const TX* img = reinterpret_cast<const TX*>(a.x) + (size_t)n * 3 * a.H * a.W;
+    for (int p = tid; p < NP; p += 256) {
+        const int py = p / FW, pxx = p - py * FW;
+        const int Y = y0 + py, X = x0 + pxx;
+        const bool ok = (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+        bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (__bf16)to_f32(img[((size_t)c * a.H + Y) * a.W + X]);
+        }
+        *reinterpret_cast<bf16x4*>(P + p * 4) = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[FN][4];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int p = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int t0 = 8 * s + 2 * g, t1 = t0 + 1;            // the lane's two taps of this K step (9.. are padding)
+        bf16x8 xf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 2 * wave + (j >> 1), c = 16 * (j & 1) + p;
+            bf16x4 lo = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f}, hi = lo;
+            if (t0 < 9) lo = *reinterpret_cast<const bf16x4*>(P + ((r + t0 / 3) * FW + c + t0 % 3) * 4);
+            if (t1 < 9) hi = *reinterpret_cast<const bf16x4*>(P + ((r + t1 / 3) * FW + c + t1 % 3) * 4);
+            xf[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][s], xf[j], acc[i][j], 0, 0, 0);
+    }
+
+    const bool silu = a.act == YDET_ACT_SILU;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oi = i0 + 2 * wave + (j >> 1), oj = j0 + 16 * (j & 1) + p;
+        if (oi >= a.Ho || oj >= a.Wo) continue;
+        char* yrow = a.y + ((((size_t)n * a.Ho + oi) * a.Wo + oj) * a.y_ld + a.y_coff) * 2;
+#pragma unroll
+        for (int h = 0; h < FN / 2; ++h) {
+            const int co = 32 * h + 8 * g;
+            if (co >= a.Cout) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * h][j][e]; v[4 + e] = acc[2 * h + 1][j][e]; }
+            if (a.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co);
+                const float4 b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e];
+                if (silu) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+                else x = x > 0.f ? x : x * a.slope;
+                o[e] = (__bf16)x;
+            }
+            *reinterpret_cast<bf16x8*>(yrow + co * 2) = o;
+        }
+    }
+}
+
+}  // namespace
+
+int ydet_launch_rgb_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {
+    YDET_CHECK_ARG(d != nullptr && d->x && d->w && d->y, "rgb_conv3x3: null pointer");
+    YDET_CHECK_ARG(dtype_ok(x_dtype), "rgb_conv3x3: bad image dtype");
+    YDET_CHECK_ARG(d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "rgb_conv3x3: bf16 weights and output only");
+    YDET_CHECK_ARG(d->N > 0 && d->N <= 65535 && d->H > 0 && d->W > 0, "rgb_conv3x3: image %d x %d x %d", d->N, d->H, d->W);
+    YDET_CHECK_ARG(d->Cin == 3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W,
+                   "rgb_conv3x3: 3 image channels and a 3x3 / stride 1 / pad 1 convolution only");
+    YDET_CHECK_ARG(d->Cout >= 8 && d->Cout <= 64 && d->Cout % 8 == 0 && d->cout_pad >= 64, "rgb_conv3x3: Cout=%d (multiple of 8, <= 64)", d->Cout);
+    YDET_CHECK_ARG(d->kp == 64, "rgb_conv3x3: weights must be packed for 4 input channels per tap (kp = 64)");
+    YDET_CHECK_ARG(d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld,
+                   "rgb_conv3x3: output slice (y_ld, y_coff multiples of 8)");
+    YDET_CHECK_ARG(d->res == nullptr && d->post_scale == nullptr && d->y2 == nullptr, "rgb_conv3x3: no residual / second stage / destination");
+    YDET_CHECK_ARG(((uintptr_t)d->x & 3) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->y & 15) == 0 &&
+                       ((uintptr_t)d->bias & 15) == 0, "rgb_conv3x3: pointer alignment");
+    StemArgs a;
+    a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
+    a.tiles_x = (a.Wo + TW - 1) / TW; a.tiles_y = (a.Ho + TH - 1) / TH;
+    a.act = d->act;
+    a.slope = d->act == YDET_ACT_NONE ? 1.0f : d->slope;
+    const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)a.N);
+    const bool wide = d->Cout > 32;
+    if (x_dtype == YDET_F32) {
+        if (wide) hipLaunchKernelGGL((rgb_conv3x3_kernel<float, 4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((rgb_conv3x3_kernel<float, 2>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (wide) hipLaunchKernelGGL((rgb_conv3x3_kernel<__bf16, 4>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((rgb_conv3x3_kernel<__bf16, 2>), grid, dim3(256), 0, stream, a);
+    }
+    YDET_CHECK_LAUNCH("rgb_conv3x3_kernel");
+    return YDET_OK;
+}
+
+extern "C" int ydet_rgb_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream) {
+    clear_error();
+    return ydet_launch_rgb_conv(d, x_dtype, as_stream(stream));
+}
+
+namespace {
 }  // namespace
 
 int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {

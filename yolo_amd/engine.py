@@ -464,6 +464,44 @@ class Graph:
             self.ext_in = [j - 1 if j > idx else j for j in self.ext_in]
             i = idx
 
+    # ---- NCHW edge + first 3x3 convolution over the 3 image channels as one kernel --------------------------------------
+    def fuse_rgb_stem(self):
+        """`input_nchw` (3 channels, no Focus) read only by a 3x3 / stride 1 / pad 1 convolution with at most 64 output
+        channels (bf16): both become one "rgb_conv" op that reads the NCHW image directly."""
+        if self.dt != _ffi.BF16:
+            return
+        for idx, (kind, e) in enumerate(list(self.ops)):
+            if kind != "nchw2nhwc" or e["focus"] or e["C"] != 3:
+                continue
+            root = e["y"].resolve()[0]
+            readers = []
+            for k2, a2 in self.ops:
+                ts = [a2[key] for key in ("x", "res", "other") if isinstance(a2.get(key), T)]
+                if k2 in ("bottleneck", "c3tail"):
+                    ts.append(a2["cv1"]["x"])
+                if a2 is not e and any(t.resolve()[0] is root for t in ts):
+                    readers.append((k2, a2))
+            if len(readers) != 1 or readers[0][0] != "conv" or any(v.resolve()[0] is root for v in self.outputs.values() if isinstance(v, T)):
+                continue
+            A = readers[0][1]
+            pc, y = A["pc"], A["y"]
+            if not ((pc.KH, pc.KW, A["stride"], A["pad"]) == (3, 3, 1, 1) and pc.Cout % 8 == 0 and pc.Cout <= 64 and y.dtype == _ffi.BF16
+                    and all(A.get(k) is None for k in ("res", "post", "y2", "up", "pre")) and not y.resolve()[0].external):
+                continue
+            cin = pc.Cin                                   # channels the weights were packed for (3 padded to the vector)
+            w = pc.w[:, :9 * cin].reshape(pc.cout_pad, 9, cin)[:, :, :4].reshape(pc.cout_pad, 36)
+            w4 = torch.zeros(max(pc.cout_pad, 64), 64, device=w.device, dtype=w.dtype)
+            w4[:pc.cout_pad, :36] = w
+            b4 = torch.zeros(max(pc.cout_pad, 64), device=pc.b.device)
+            b4[:pc.cout_pad] = pc.b
+            npc = PackedConv(w4.contiguous(), b4, 4, pc.Cout, 3, 3, 64, w4.shape[0], cin_real=3)
+            self.keep.append(npc)
+            self.ops[idx] = ("rgb_conv", dict(y=y, pc=npc, N=e["N"], C=3, H=e["H"], W=e["W"], act=A["act"], slope=A["slope"],
+                                              src_dtype=e["src_dtype"]))
+            j = next(i for i, (_, r) in enumerate(self.ops) if r is A)
+            del self.ops[j]
+            self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
+
     # ---- finalize ------------------------------------------------------------------------------
     def finalize(self, replicas=1):
         return Plan(self, replicas)
@@ -483,6 +521,7 @@ class Plan:
         self.R = replicas
         g.fuse_upsamples()
         g.fuse_pointwise_followers()
+        g.fuse_rgb_stem()
         n = len(g.ops)
         self.patch_in = list(g.ext_in)  # op indices whose source is a caller-supplied NCHW input
         self.patch_out = []       # (op index, field, storage) of external NHWC buffers
@@ -544,14 +583,14 @@ class Plan:
             hd.grid_transposed, hd.stride = a["transposed"], a["det_stride"]
             for k, v in enumerate(a["anchors"]):
                 hd.anchor_wh[k] = v
-        elif kind == "focus_conv":
-            op.kind = _ffi.OP_FOCUS_CONV
+        elif kind in ("focus_conv", "rgb_conv"):
+            op.kind = _ffi.OP_FOCUS_CONV if kind == "focus_conv" else _ffi.OP_RGB_CONV
             d, pc = op.conv, a["pc"]
             root, off = a["y"].resolve()
             d.y, d.w, d.bias = self._ptr(root, arena, i, "cy", record), pc.w.data_ptr(), pc.b.data_ptr()
             d.N, d.H, d.W, d.Cin = a["N"], a["H"], a["W"], a["C"]
             d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, 3, 3, 1, 1
-            d.Ho, d.Wo = a["H"] // 2, a["W"] // 2
+            d.Ho, d.Wo = (a["H"] // 2, a["W"] // 2) if kind == "focus_conv" else (a["H"], a["W"])
             d.y_ld, d.y_coff, d.kp, d.cout_pad = root.ld, off, pc.kp, pc.cout_pad
             d.act, d.slope, d.in_dtype, d.out_dtype = a["act"], a["slope"], _ffi.BF16, root.dtype
             op.iarg3 = a["src_dtype"]
@@ -652,11 +691,11 @@ class Plan:
                for st in self._ext_storages}
         for i, x in zip(self.patch_in, xs):
             op0 = self.op_lists[0][i]
-            focus = op0.kind == _ffi.OP_FOCUS_CONV
+            focus = op0.kind in (_ffi.OP_FOCUS_CONV, _ffi.OP_RGB_CONV)      # first layers that read the image themselves
             if x.dtype == torch.uint8:
-                # raw pixel values: the fused first layer scales them by 1/255 while loading (val.py:68-69 folded in);
+                # raw pixel values: the fused Focus layer scales them by 1/255 while loading (val.py:68-69 folded in);
                 # any other first layer gets the scaled fp32 image
-                if not focus:
+                if op0.kind != _ffi.OP_FOCUS_CONV:
                     x = x.float() / 255.0
             elif x.dtype not in (torch.float32, torch.bfloat16):
                 x = x.float()
@@ -832,6 +871,11 @@ def _op_info(kind, a):
         Cc = x.C
         return dict(kind="conv", label=f"conv_bottleneck_c{Cc}", flops=2.0 * px * Cc * Cc * 10,
                     bytes=px * Cc * 2 * 2 + 10 * Cc * Cc * 2, shape=(x.N, x.H, x.W, Cc, Cc, 3, 1))
+    if kind == "rgb_conv":
+        y, pc = a["y"], a["pc"]
+        return dict(kind="conv", label="conv_rgb3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 27,
+                    bytes=a["N"] * 3 * a["H"] * a["W"] * 4 + y.N * y.H * y.W * y.C * esz(y),
+                    shape=(a["N"], a["H"], a["W"], 3, pc.Cout, 3, 1))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
         return dict(kind="conv", label="conv_focus3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
