@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--only", default="", help="run only the configurations whose model tag is this (e.g. v4)")
     args = ap.parse_args()
     from helpers import build_fa
     from yolo_amd import engine
@@ -33,6 +34,8 @@ def main():
     dev = torch.device("cuda:0")
     for tag, size, batch in (("v3tiny", 416, 1), ("v3tiny", 416, 64), ("v2d19", 416, 32), ("v3spp", 608, 64), ("v4", 608, 64),
                              ("v2r50", 416, 32), ("v2slim", 416, 32)):
+        if args.only and tag != args.only:
+            continue
         net = build_fa(tag, size).to(dev)
         x = images(batch, size, seed=1, kind="randn").to(dev)
         with torch.no_grad():

@@ -192,6 +192,72 @@ __global__ __launch_bounds__(256) void decode_fa_kernel(const FAArgs a) {
     reinterpret_cast<float4*>(a.boxes)[gid] = bb;
 }
 
+// The same decode with coalesced traffic: a workgroup owns `cells` consecutive cells of one level of one image.  Their
+// head rows are one contiguous run of the NHWC map and their A boxes each one contiguous run of both outputs, so the
+// rows are staged through LDS in 16-byte pieces, every thread decodes boxes out of LDS (the arithmetic above, value for
+// value), and the scores leave through LDS as contiguous pieces.  One thread per box read 25 scattered values and wrote
+// 20 strided ones: a wave's load touched some fifty cache lines per instruction.
+struct FATileArgs {
+    FAArgs f;
+    int level, cells, tiles;     // tiles per image of this level
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_fa_tiled_kernel(const FATileArgs ta) {
+    extern __shared__ __attribute__((aligned(16))) float fa_lds[];
+    const FAArgs& a = ta.f;
+    const int l = ta.level, n = blockIdx.y;
+    const int hw = a.H[l] * a.W[l], ld = a.ld[l];
+    const int cell0 = blockIdx.x * ta.cells;
+    const int nc_ = min(ta.cells, hw - cell0);           // cells of this tile
+    float* rows = fa_lds;                                 // [cells][ld]
+    float* outs = fa_lds + (size_t)ta.cells * ld;         // [cells * A][nc]
+    const T* src = reinterpret_cast<const T*>(a.head[l]) + ((size_t)n * hw + cell0) * ld;
+    for (int i = threadIdx.x; i < nc_ * ld; i += 256) rows[i] = to_f32(src[i]);
+    __syncthreads();
+    const int nb = nc_ * a.A;
+    const size_t box0 = (size_t)n * a.box_off[a.nl] + a.box_off[l] + (size_t)cell0 * a.A;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const int lc = b / a.A, an = b - lc * a.A;
+        const int cell = cell0 + lc;
+        const int row = cell / a.W[l], col = cell - row * a.W[l];
+        const float* px = rows + (size_t)lc * ld;
+        const float conf = sigmoidf_(px[an]);
+        const float* cl = px + a.A + an * a.nc;
+        float mx = -INFINITY;
+        for (int c = 0; c < a.nc; ++c) mx = fmaxf(mx, cl[c]);
+        float sum = 0.f;
+        for (int c = 0; c < a.nc; ++c) sum += expf(cl[c] - mx);
+        float* sc = outs + (size_t)b * a.nc;
+        for (int c = 0; c < a.nc; ++c) sc[c] = expf(cl[c] - mx) / sum * conf;
+        const float* t = px + a.A * (1 + a.nc) + an * 4;
+        const float gx = a.transposed ? (float)(cell / a.H[l]) : (float)col;
+        const float gy = a.transposed ? (float)(cell % a.H[l]) : (float)row;
+        const float aw = a.anchor[l][2 * an], ah = a.anchor[l][2 * an + 1];
+        float cx, cy, w, h;
+        if (a.mode == 0) {
+            cx = (sigmoidf_(t[0]) + gx) * a.mult;
+            cy = (sigmoidf_(t[1]) + gy) * a.mult;
+            w = expf(t[2]) * aw * a.mult;
+            h = expf(t[3]) * ah * a.mult;
+        } else {
+            cx = (sigmoidf_(t[0]) + gx) * a.mult;
+            cy = (sigmoidf_(t[1]) + gy) * a.mult;
+            w = expf(t[2]) * aw;
+            h = expf(t[3]) * ah;
+        }
+        float4 bb;
+        bb.x = fminf(fmaxf((cx - w / 2.0f) / a.input_size, 0.f), 1.f);
+        bb.y = fminf(fmaxf((cy - h / 2.0f) / a.input_size, 0.f), 1.f);
+        bb.z = fminf(fmaxf((cx + w / 2.0f) / a.input_size, 0.f), 1.f);
+        bb.w = fminf(fmaxf((cy + h / 2.0f) / a.input_size, 0.f), 1.f);
+        reinterpret_cast<float4*>(a.boxes)[box0 + b] = bb;
+    }
+    __syncthreads();
+    float* dst = a.scores + box0 * a.nc;
+    for (int i = threadIdx.x; i < nb * a.nc; i += 256) dst[i] = outs[i];
+}
+
 }  // namespace
 
 extern "C" int ydet_decode_v5(const ydet_v5_level* levels, int nl, int N, int na, int no, int grid_transposed,
@@ -268,6 +334,30 @@ extern "C" int ydet_decode_v2v3(const ydet_fa_level* levels, int nl, int N, int 
     }
     for (int l = nl; l <= kMaxLevels; ++l) a.box_off[l] = (int)off;
     a.total = (long long)N * off;
+    // tiled form: one launch per level, as many cells per workgroup as 48 KB of LDS hold (rows + scores), at most 64
+    bool tiled = N <= 65535;
+    int cells[kMaxLevels];
+    for (int l = 0; l < nl && tiled; ++l) {
+        const size_t per_cell = ((size_t)a.ld[l] + (size_t)A * nc) * sizeof(float);
+        cells[l] = (int)((48 * 1024) / per_cell);
+        if (cells[l] > 64) cells[l] = 64;
+        if (cells[l] < 8) tiled = false;
+    }
+    if (tiled) {
+        for (int l = 0; l < nl; ++l) {
+            FATileArgs ta;
+            ta.f = a; ta.level = l; ta.cells = cells[l];
+            ta.tiles = (a.H[l] * a.W[l] + cells[l] - 1) / cells[l];
+            const size_t lds = (size_t)cells[l] * ((size_t)a.ld[l] + (size_t)A * nc) * sizeof(float);
+            const dim3 grid((unsigned)ta.tiles, (unsigned)N);
+            if (head_dtype == YDET_BF16)
+                hipLaunchKernelGGL(decode_fa_tiled_kernel<__bf16>, grid, dim3(256), lds, as_stream(stream), ta);
+            else
+                hipLaunchKernelGGL(decode_fa_tiled_kernel<float>, grid, dim3(256), lds, as_stream(stream), ta);
+            YDET_CHECK_LAUNCH("decode_fa_tiled_kernel");
+        }
+        return YDET_OK;
+    }
     const long long grid = (a.total + 255) / 256;
     YDET_CHECK_ARG(grid > 0 && grid < 0x7fffffffLL, "decode_v2v3: grid");
     if (head_dtype == YDET_BF16)

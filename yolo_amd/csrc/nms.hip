@@ -668,7 +668,9 @@ __global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
 
 constexpr int kFaMaxWords = 2048;  // up to 131072 boxes per class segment
 
-__global__ __launch_bounds__(256) void fa_nms_kernel(const FAArgs a) {
+constexpr int kFaNmsThreads = 1024;   // four threads per later box when a chunk's survivors are applied (long class segments)
+
+__global__ __launch_bounds__(kFaNmsThreads) void fa_nms_kernel(const FAArgs a) {
     __shared__ NmsShared sh;
     __shared__ u64 removed[kFaMaxWords], kept[kFaMaxWords];
     const int img = blockIdx.y, c = blockIdx.x;
@@ -678,9 +680,9 @@ __global__ __launch_bounds__(256) void fa_nms_kernel(const FAArgs a) {
     const unsigned off = fa_class_offset(count, c);
     const unsigned* sorted = a.sorted + (size_t)img * a.n + off;
     const float4* boxes = reinterpret_cast<const float4*>(a.boxes) + (size_t)img * a.n;
-    greedy_nms_block<true>(cnt, a.thr, [&](int s) { return boxes[sorted[s]]; }, sh, removed, kept);
+    greedy_nms_block<true, kFaNmsThreads>(cnt, a.thr, [&](int s) { return boxes[sorted[s]]; }, sh, removed, kept);
     uint8_t* keep = a.keep + (size_t)img * a.n;
-    for (int s = threadIdx.x; s < cnt; s += 256)
+    for (int s = threadIdx.x; s < cnt; s += kFaNmsThreads)
         if ((kept[s >> 6] >> (s & 63)) & 1ull) keep[sorted[s]] = 1;
 }
 
@@ -905,7 +907,7 @@ extern "C" int ydet_nms_perclass(const float* boxes, const float* scores, int N,
     hipLaunchKernelGGL(fa_score_kernel, dim3(g1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(fa_scatter_kernel, dim3(g1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(fa_rank_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nc, (unsigned)N), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(fa_nms_kernel, dim3((unsigned)nc, (unsigned)N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(fa_nms_kernel, dim3((unsigned)nc, (unsigned)N), dim3(kFaNmsThreads), 0, s, a);
     YDET_CHECK_LAUNCH("nms_perclass kernels");
     return YDET_OK;
 }
