@@ -597,12 +597,26 @@ struct FAArgs {
     unsigned* sorted;     // [N][n]  same, sorted by descending score inside each class
 };
 
-// argmax class (first maximum), threshold, per-class population count.
+// argmax class (first maximum), threshold, per-class population count.  The 256 boxes of a workgroup are one
+// contiguous run of the score matrix: it is staged through LDS in coalesced order (a thread reading its own nc values
+// straight from memory touches a different cache line than each of its neighbours).
+constexpr int kFaScoreMaxNc = 40;     // 256 * nc floats of LDS; wider score rows take the direct path
+
 __global__ __launch_bounds__(256) void fa_score_kernel(const FAArgs a) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)a.N * a.n) return;
+    __shared__ float tile[256 * kFaScoreMaxNc];
+    const long long total = (long long)a.N * a.n;
+    const long long g0 = (long long)blockIdx.x * 256;
+    const long long gid = g0 + threadIdx.x;
+    const bool staged = a.nc <= kFaScoreMaxNc;
+    if (staged) {
+        const int rows = (int)min((long long)256, total - g0);
+        const float* src = a.scores + (size_t)g0 * a.nc;
+        for (int i = threadIdx.x; i < rows * a.nc; i += 256) tile[i] = src[i];
+        __syncthreads();
+    }
+    if (gid >= total) return;
     const int img = (int)(gid / a.n);
-    const float* s = a.scores + (size_t)gid * a.nc;
+    const float* s = staged ? tile + threadIdx.x * a.nc : a.scores + (size_t)gid * a.nc;
     float best = s[0];
     int bj = 0;
     for (int j = 1; j < a.nc; ++j) {
