@@ -51,7 +51,7 @@ def main():
                     help="per-op events (kernel durations for the roofline object) are recorded on every E-th timed "
                          "step: an event costs 2-3 us of stream time, 55 of them per step are 5 %% of it, and "
                          "such a step runs alone on the GPU (it drains the pipeline of batches)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="batches are issued round-robin on this many HIP streams (each with its own plan / activation "
                          "arena), so the tail of one batch's kernels and its small-grid NMS overlap the next batch; the "
                          "steps that carry per-op events run alone")
