@@ -134,7 +134,7 @@ def test_nms_v5_golden(golden, tag):
 
 
 @pytest.mark.parametrize("case", ["ties_all_equal", "ties_threshold_bin", "flat_classes", "empty", "one", "classes",
-                                  "nan_scores"])
+                                  "classes_best_many", "classes_ml_many", "nan_scores"])
 def test_nms_v5_edge_cases(case):
     g = _gen(11, case)
     kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
@@ -159,6 +159,15 @@ def test_nms_v5_edge_cases(case):
     elif case == "classes":
         pred = clustered_predictions(2, 800, 6, seed=5)
         kw = dict(conf_thres=0.2, iou_thres=0.45, classes=[1, 4])
+    elif case in ("classes_best_many", "classes_ml_many"):
+        # a class filter with far more than max_det rows above conf: in best-class mode a row whose best class is
+        # filtered out has no candidate even if one of the kept classes scores above conf (yolov5_official/utils.py:
+        # 160-166), and must not be counted when the pre-selection sizes its score cut
+        pred = clustered_predictions(2, 6000, 6, seed=12, obj_pass=0.9)
+        pred[..., 5:] = torch.rand(2, 6000, 6, generator=g)
+        kw = dict(conf_thres=0.05, iou_thres=0.45, classes=[1, 4], multi_label=case == "classes_ml_many")
+        ref = O.non_max_suppression(pred.numpy(), **kw)
+        assert all(len(r) > 20 for r in ref)
     else:   # NaN / inf inputs must not hang or crash; compared to the oracle on the finite image only
         pred = clustered_predictions(2, 400, 3, seed=6)
         pred[1, ::7, 4] = float("nan")

@@ -317,3 +317,26 @@ def test_planner_folds_nearest_upsamples_into_pointwise_convs():
         ups = [(a["x"].C, a["up"][1], a["up"][0].H * 2 == a["x"].H) for k, a in g.ops if k == "conv" and a.get("up")]
         assert ups == [(512, 256, True), (256, 128, True)]
         assert [g.ops[i][0] for i in g.ext_in] in (["focus_conv"], ["nchw2nhwc"])
+
+
+def test_v5s_fuse_and_augment_torch_face_match_golden(golden):
+    """Model.fuse() (yolov5_official/model.py:258-265) and forward(augment=True) (:208-251) on CPU tensors against the
+    reference's own outputs; a fused model still plans (every block reads its BatchNorm through a guard)."""
+    from yolo_amd import engine
+    from yolo_amd.yolov5_official.modules import Conv
+    g = golden("g11_v5s_fuse_augment")
+    m = build_v5s(20)
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x)[0].numpy(), g["z_plain"], rtol=1e-4, atol=1e-4)
+        za, none = m(x.clone(), augment=True)
+        assert none is None
+        np.testing.assert_allclose(za.numpy(), g["z_aug"], rtol=1e-4, atol=2e-4)
+        m.fuse()
+        assert not any(hasattr(mod, "bn") for mod in m.modules() if type(mod) is Conv)
+        np.testing.assert_allclose(m(x)[0].numpy(), g["z_fused"], rtol=1e-4, atol=2e-4)
+    for comp in ("bf16", "fp32"):
+        gr = engine.Graph("cpu", comp)
+        m._lower(gr, 2, 3, 96, 128)
+        kinds = [k for k, _ in gr.finalize().g.ops]
+        assert kinds.count("head_decode") == 3 and (comp == "fp32" or kinds.count("c3tail") == 1)

@@ -54,7 +54,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     from oracle import postproc as O
-    from yolo_amd.synthetic import V2R50_HEAD_SCALE, _gen, clustered_predictions, images, init_deterministic
+    from yolo_amd.synthetic import _gen, clustered_predictions, images, init_deterministic, scale_fa_heads
 
     def save(name, **arrs):
         if not name.startswith(args.only):
@@ -122,10 +122,9 @@ def main():
         cls = getattr(sys.modules[modname], cls_name)
         net = cls(size, 20, False, anchor_size=cfg["anchor_size_voc"])
         init_deterministic(net, seed=0)
-        if modname == "models.v2r50":
-            # the residual trunk lets activations grow with random BatchNorm gains: without this the 416 head map
-            # reaches +-50 and most scores saturate to exactly 1.0 (ties whose visiting order numpy leaves open)
-            net.pred.weight.data *= V2R50_HEAD_SCALE
+        # residual trunks let activations grow with random BatchNorm gains: unscaled, most scores of these detectors
+        # saturate to exactly 1.0 (ties whose visiting order numpy leaves open)
+        scale_fa_heads(net, modname.split(".")[-1])
         return net
 
     def sample(a, step=53):
@@ -311,6 +310,23 @@ def main():
     with torch.no_grad():
         zc, _ = mc(images(1, 64, seed=65))
     save("g6_v5s_compat_nc20_64", x_seed=65, z=zc.numpy())
+
+    # ================= G11: Model.fuse() and forward(augment=True) (yolov5_official/model.py:201-265) ===
+    # fuse() ends in an undefined self.info() (AttributeError) AFTER every Conv has been fused: caught here.
+    m = rmodel.Model(cfg_path, nc=20).eval()
+    init_deterministic(m, seed=0, head_convs=list(m.model[-1].m))
+    xa = torch.rand(2, 3, 96, 128, generator=_gen(66, "g11aug"))
+    with torch.no_grad():
+        z_plain, _ = m(xa)
+        z_aug, none = m(xa.clone(), augment=True)
+        assert none is None
+        try:
+            m.fuse()
+        except AttributeError as e:
+            notes["fuse"] = f"reference fuse() raised after fusing: {e}"
+        assert not any(hasattr(mod, "bn") for mod in m.modules() if type(mod) is rmods.Conv)
+        z_fused, _ = m(xa)
+    save("g11_v5s_fuse_augment", z_plain=z_plain.numpy(), z_aug=z_aug.numpy(), z_fused=z_fused.numpy(), x=xa.numpy())
 
     # ================= G7: metric helpers ==============================================================
     g = _gen(0, "g7")

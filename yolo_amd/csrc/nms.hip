@@ -247,9 +247,23 @@ __global__ __launch_bounds__(256) void v5_rowmax_kernel(const V5Args a) {
         const float* p = tile + r * a.no;
         obj = p[4];
         const int c0 = half ? a.nc >> 1 : 0, c1 = half ? a.nc : a.nc >> 1;
-        if (a.class_mask) {
+        if (a.class_mask && a.multi) {
             for (int c = c0; c < c1; ++c)
                 if (a.class_mask[c]) m = fmaxf(m, p[5 + c] * obj);
+        } else if (a.class_mask) {
+            // best-class mode picks the best class over ALL classes and filters afterwards
+            // (yolov5_official/utils.py:160-166): a row whose best class is masked out has no candidate at all
+            int bj = -1;
+            for (int c = c0; c < c1; ++c) {
+                const float v = p[5 + c] * obj;
+                if (bj < 0 || v > m) { m = v; bj = c; }
+            }
+            const float mo = __shfl_xor(m, 1);
+            const int bo = __shfl_xor(bj, 1);
+            // first maximum: the lower half wins ties (an empty half has bj < 0)
+            const bool other = bo >= 0 && (bj < 0 || (half ? !(m > mo) : mo > m));
+            if (other) { m = mo; bj = bo; }
+            if (bj < 0 || !a.class_mask[bj]) m = -INFINITY;
         } else {
             for (int c = c0; c < c1; ++c) m = fmaxf(m, p[5 + c] * obj);
         }

@@ -13,9 +13,26 @@ import torch
 import torch.nn as nn
 
 
-# The v2r50 fixtures and tests scale the prediction conv's weights by this after init_deterministic: the residual
-# trunk amplifies activations under random BatchNorm gains, and unscaled head maps saturate most scores to 1.0.
-V2R50_HEAD_SCALE = 0.05
+# Fixtures, tests and benchmarks of the residual-trunk detectors scale their prediction convs' weights by these after
+# init_deterministic: a residual trunk amplifies activations under random BatchNorm gains (the unscaled head maps of
+# the Darknet-53 models reach 1e6), which saturates most scores to exactly 1.0 -- ties whose visiting order numpy's
+# argsort leaves open.  tag -> (names of the prediction convs, factor).
+FA_HEAD_SCALE = {
+    "v2r50": (("pred",), 0.05),
+    "v3spp": (("pred_1", "pred_2", "pred_3"), 1e-6),
+    "v3": (("pred_1", "pred_2", "pred_3"), 2e-6),
+    "v4": (("head_det_1", "head_det_2", "head_det_3"), 4e-6),
+}
+V2R50_HEAD_SCALE = FA_HEAD_SCALE["v2r50"][1]
+
+
+@torch.no_grad()
+def scale_fa_heads(net, tag):
+    """Apply FA_HEAD_SCALE[tag] to `net` (a no-op for detectors without an entry)."""
+    names, factor = FA_HEAD_SCALE.get(tag, ((), 1.0))
+    for n in names:
+        getattr(net, n).weight.mul_(factor)
+    return net
 
 
 def _gen(seed, key):

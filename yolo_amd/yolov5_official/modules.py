@@ -60,6 +60,12 @@ class Conv(nn.Module):
                       out=out)
 
 
+def _cb(m):
+    """(convolution, BatchNorm or None) of a Conv block: Model.fuse() folds the BatchNorm into the convolution's
+    weights and bias and deletes the attribute."""
+    return m.conv, getattr(m, "bn", None)
+
+
 def DWConv(c1, c2, k=1, s=1, act=True):
     return Conv(c1, c2, k, s, g=math.gcd(c1, c2), act=act)
 
@@ -81,7 +87,7 @@ class Bottleneck(nn.Module):
     def lower(self, g, x, out=None):
         a1, a2 = activation_code(self.cv1.act), activation_code(self.cv2.act)
         if a1 == a2 and a1[0] != _ffi.ACT_NONE:
-            return g.bottleneck(x, (self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn), *a1, add=self.add, out=out)
+            return g.bottleneck(x, _cb(self.cv1), _cb(self.cv2), *a1, add=self.add, out=out)
         return self.cv2.lower(g, self.cv1.lower(g, x), out=out, res=x if self.add else None)
 
 
@@ -144,20 +150,19 @@ class C3(nn.Module):
                 # 32- and 64-channel bottlenecks run as one kernel that must not work in place (it reads a halo): the sibling
                 # conv sends cv1(x) to a buffer of its own and cv2(x) to what becomes the second half of the concat
                 # buffer; the last bottleneck's output becomes the first half
-                _, (y, y2) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1, separate=True)
+                _, (y, y2) = g.conv_siblings(x, [_cb(self.cv1), _cb(self.cv2)], *a1, separate=True)
                 for b in list(self.m)[:-1]:
                     y = b.lower(g, y)
                 last = list(self.m)[-1]
                 la = (activation_code(last.cv1.act), activation_code(last.cv2.act), activation_code(self.cv3.act))
-                if c_ == 32 and la[0] == la[1] == la[2] == a1 and a1[0] != _ffi.ACT_NONE and hasattr(self.cv3, "bn"):
+                if c_ == 32 and la[0] == la[1] == la[2] == a1 and a1[0] != _ffi.ACT_NONE:
                     # the last bottleneck, the concat and cv3 as one kernel (32-channel stage only)
-                    out = g.c3_tail(y, (last.cv1.conv, last.cv1.bn), (last.cv2.conv, last.cv2.bn), y2,
-                                    (self.cv3.conv, self.cv3.bn), *a1, add=last.add)
+                    out = g.c3_tail(y, _cb(last.cv1), _cb(last.cv2), y2, _cb(self.cv3), *a1, add=last.add)
                     if out is not None:
                         return out
                 y = last.lower(g, y)
                 return self.cv3.lower(g, g.cat([y, y2]))
-            cat, (y, _) = g.conv_siblings(x, [(self.cv1.conv, self.cv1.bn), (self.cv2.conv, self.cv2.bn)], *a1)
+            cat, (y, _) = g.conv_siblings(x, [_cb(self.cv1), _cb(self.cv2)], *a1)
             for b in self.m:
                 b.lower(g, y, out=y)
             return self.cv3.lower(g, cat)
