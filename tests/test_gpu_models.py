@@ -649,7 +649,7 @@ def test_v5s_forward_augment_reference(golden):
     assert none is None and tuple(z.shape) == g["z_aug"].shape
     assert rel_err(z[..., 4:].cpu().numpy(), g["z_aug"][..., 4:]) < 1e-3
     assert rel_err(z[..., :4].cpu().numpy(), g["z_aug"][..., :4]) < 1e-3
-    assert len(m._plans().plans) == 3             # one plan per scale
+    assert len(m._plans().plans) == 2             # 96x128 (scales 1 and 0.83, padded back up) and 96x96 (scale 0.67)
 
 
 # ---- drop-in under the reference's own import names --------------------------------------------------------------------
