@@ -276,6 +276,20 @@ int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float conf_thres, 
                 const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* ydet_nms_v5 for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): no counterpart in the reference.  Same arguments, same kernels and bit-identical
+ * results, but the workspace is a YDET_NMS_V5_STATIC_BYTES device array built into the library (each GPU the library
+ * runs on holds its copy until the process ends), and the call itself allocates nothing.  Shapes whose workspace
+ * (ydet_nms_v5_workspace_bytes) exceeds that size are rejected with YDET_ERR_WORKSPACE: 64 images x 25 200 boxes fit.
+ * The first call on a device resolves the array's address (one hipGetSymbolAddress; make that call outside a graph
+ * capture).  All calls on one GPU share the one array: calls that overlap on a GPU (two streams, two threads) race;
+ * serialise them or use ydet_nms_v5 with separate workspaces. */
+#define YDET_NMS_V5_STATIC_BYTES (16u << 20)
+int ydet_nms_v5_static(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                       int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
+                       const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
+                       void* stream);
+
 /* postprocess + nms: utils/utils.py:101-133 and :15-42.
  * boxes [N, n, 4], scores [N, n, nc] fp32.  Per image: cls = argmax (first maximum),
  * score = max, candidates have score >= conf_thresh; per class greedy NMS in descending score

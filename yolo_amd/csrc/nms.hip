@@ -10,6 +10,8 @@
 //                "i suppresses j" matrix in parallel; phase B walks the 64 rows serially (one
 //                lane) against the bitset of already-removed boxes; phase C applies the chunk's
 //                kept boxes to every later box in parallel.
+#include <mutex>
+
 #include "ydet_internal.h"
 
 using namespace ydet;
@@ -854,11 +856,10 @@ extern "C" size_t ydet_nms_v5_workspace_bytes(int N, int nboxes, int no) {
     return v5_ws_layout(N, nboxes, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
-                           int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
-                           const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
-                           void* workspace, size_t workspace_bytes, void* stream) {
-    clear_error();
+static int nms_v5_run(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                      int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
+                      const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
+                      void* workspace, size_t workspace_bytes, void* stream) {
     YDET_CHECK_ARG(pred && out_det && out_count && workspace, "nms_v5: null pointer");
     YDET_CHECK_ARG(N > 0 && nboxes > 0 && no >= 6, "nms_v5: N=%d nboxes=%d no=%d", N, nboxes, no);
     YDET_CHECK_ARG(no <= kTileFloats, "nms_v5: no=%d exceeds %d", no, kTileFloats);
@@ -900,6 +901,64 @@ extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float c
     hipLaunchKernelGGL(v5_nms_kernel, dim3((unsigned)N), dim3(kNmsThreads), 0, s, a);
     YDET_CHECK_LAUNCH("nms_v5 kernels");
     return YDET_OK;
+}
+
+extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                           int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
+                           const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    clear_error();
+    return nms_v5_run(pred, N, nboxes, no, conf_thres, iou_thres, multi_label, agnostic, max_nms, max_det, max_wh, class_mask,
+                      row_max, out_det, out_count, workspace, workspace_bytes, stream);
+}
+
+// ---- the same operator for callers that must not allocate ---------------------------------------------------------
+// The workspace of ydet_nms_v5 (row maxima, per-image records, candidate list, sorted keys and boxes) lives in a
+// device array that is part of the library's code object: every GPU the library runs on holds its own copy until the
+// process ends.  In host code the array's NAME is only a handle: its device address is asked for once per device
+// (hipGetSymbolAddress, with that device current) and kept; kernels are given that pointer like any other workspace.
+constexpr size_t kStaticNmsBytes = (size_t)YDET_NMS_V5_STATIC_BYTES;
+static __device__ __align__(256) unsigned char g_nms_scratch[kStaticNmsBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices];      // per device: address of that device's copy of g_nms_scratch (null: not asked yet)
+
+int nms_scratch_for_current_device(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+        return fail(YDET_ERR_LAUNCH, "nms_v5_static: cannot tell the current device (%d)", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_nms_scratch));
+        if (e != hipSuccess || !p)
+            return fail(YDET_ERR_LAUNCH, "nms_v5_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return YDET_OK;
+}
+}  // namespace
+
+extern "C" int ydet_nms_v5_static(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                                  int multi_label, int agnostic, int max_nms, int max_det, float max_wh,
+                                  const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
+                                  void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(N > 0 && nboxes > 0, "nms_v5_static: N=%d nboxes=%d", N, nboxes);
+    const size_t need = v5_ws_layout(N, nboxes, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (need > kStaticNmsBytes)
+        return fail(YDET_ERR_WORKSPACE,
+                    "nms_v5_static: %d images x %d boxes need %zu bytes of scratch, the built-in buffer has %zu "
+                    "(use ydet_nms_v5 with a caller-owned workspace)", N, nboxes, need, kStaticNmsBytes);
+    void* ws = nullptr;
+    const int rc = nms_scratch_for_current_device(&ws);
+    if (rc != YDET_OK) return rc;
+    // nothing in the workspace has to start at zero: every word a kernel reads was written earlier in the same call
+    return nms_v5_run(pred, N, nboxes, no, conf_thres, iou_thres, multi_label, agnostic, max_nms, max_det, max_wh, class_mask,
+                      row_max, out_det, out_count, ws, kStaticNmsBytes, stream);
 }
 
 extern "C" size_t ydet_nms_perclass_workspace_bytes(int N, int n, int nc) {
