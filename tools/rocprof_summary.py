@@ -3,6 +3,8 @@
 
     rocprof_summary.py stats   <kernel_trace.csv>                      -> per-kernel duration statistics (CSV on stdout)
     rocprof_summary.py traffic <fetch_counter.csv> <write_counter.csv> <batch> <size>  -> HBM traffic per kernel (JSON)
+    rocprof_summary.py counters <counter_collection.csv> [more.csv ...]   -> per-kernel means of every counter collected,
+                                                                             plus the MFMA figures derived from them (JSON)
 
 Kernel symbols are also given the label bench.py uses for them (conv_dma<128x128,bf16->bf16>, ...), so that the two
 sources can be compared line by line.  FETCH_SIZE / WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE tallies the
@@ -33,7 +35,7 @@ def label_of(name):
             return f"conv_dma<{bn}x{bm},{dts}>"
         one = "Lb1E" in name or re.search(r"true>", name)
         return f"conv_generic<{bn}x{bm},{'1x1' if one else 'kxk'},{dts}>"
-    if "bottleneck_c32" in name and ("<true>" in name or "ILb1E" in name):
+    if "bottleneck_c32" in name and ("kernel<true" in name or "ILb1E" in name):
         return "conv_c3_tail_c32"
     for key, lab in (("focus_conv3x3", "conv_focus3x3"), ("bottleneck_c32", "conv_bottleneck_c32"), ("bottleneck_c64", "conv_bottleneck_c64"), ("decode_v5", "decode_v5"), ("v5_pick", "nms_v5_pick"),
                      ("v5_nms", "nms_v5_greedy"), ("v5_rank", "nms_v5_rank"), ("v5_rowmax", "nms_v5_rowmax"),
@@ -83,8 +85,36 @@ def traffic(fetch_csv, write_csv, batch, size):
                           batch=int(batch), size=int(size), kernels=out), indent=1))
 
 
+def counters(paths):
+    """Per kernel label: launches and the mean of each counter per launch.  Derived, where their inputs were collected:
+    mfma_busy_frac  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)
+                      (busy cycles summed over the SIMDs of the chip against the cycles the launch was active);
+    mfma_flops      = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 (the counter ticks once per 512 FLOP of a wave's bf16 MFMA)."""
+    agg = {}
+    for path in paths:
+        per = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(path)):
+            lab = label_of(r["Kernel_Name"])
+            if lab:
+                per[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for lab, cs in per.items():
+            d = agg.setdefault(lab, {})
+            for c, v in cs.items():
+                d[c] = round(sum(v) / len(v), 1)
+                d["launches"] = max(d.get("launches", 0), len(v))
+    for d in agg.values():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE"):
+            d["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+        if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in d:
+            d["mfma_flops"] = d["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0
+    print(json.dumps(dict(source="rocprofv3 --pmc passes of `bench.py --no-cpu --streams 1` (counters only, no trace in the same "
+                                 "run); means per launch; GRBM_GUI_ACTIVE is the sum over the 8 XCDs", kernels=agg), indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "counters":
+        counters(sys.argv[2:])
     else:
         traffic(*sys.argv[2:6])

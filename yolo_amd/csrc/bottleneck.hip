@@ -11,9 +11,12 @@ constexpr int TH = 8, TW = 32;                 // output tile (rows x columns)
 constexpr int PH = TH + 2, PW = TW + 2;        // patch with the 3x3 halo
 constexpr int NPIX = PH * PW;                  // 340 patch pixels
 constexpr int NGRP = (NPIX + 15) / 16;         // 22 groups of 16 patch pixels for the 1x1 stage
-constexpr int PITCH = 80;                      // bytes per patch pixel in LDS: 64 of data + 16, so that the 16-byte reads
-                                               // of 8 consecutive pixels cover all 32 banks exactly once
-constexpr int PATCH_BYTES = NGRP * 16 * PITCH; // 28160
+constexpr int PITCH = 96;                      // bytes per patch pixel in LDS: 64 of data + 32.  A ds_read_b128 is served in
+                                               // lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with pixel =
+                                               // lane & 15 and 16-byte chunk = lane >> 4 a group's sixteen 16-byte slots
+                                               // (6 * pixel + chunk) mod 16 are all different at this pitch (at 80 bytes
+                                               // seven of every eight collided)
+constexpr int PATCH_BYTES = NPIX * PITCH;      // 32640: two patches stay just inside the 64 KB of static LDS
 constexpr int NLOAD = (NPIX * 4 + 255) / 256;  // 16-byte pieces of the input patch per thread
 
 struct BneckArgs {
@@ -38,8 +41,11 @@ struct BneckArgs {
     int z_ld, z_coff, y3_ld, y3_coff, kp3;
 };
 
-__device__ __forceinline__ float act_fn(float v, bool silu, float slope) {
-    if (silu) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+// The activation is a compile-time choice: read from the arguments it became a chain of branches around every single
+// value (the kernels finish 8 to 64 values per lane and tile).
+template <bool SILU>
+__device__ __forceinline__ float act_fn(float v, float slope) {
+    if constexpr (SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
     return v > 0.f ? v : v * slope;
 }
 
@@ -47,15 +53,17 @@ __device__ __forceinline__ float act_fn(float v, bool silu, float slope) {
 // yolov5_official/modules.py:252-253).  The eight channels a lane has just finished for its pixel ARE the B fragment of
 // cv3's first K step, the other half's eight channels (one 16-byte load) the second: cv3 runs on the tile in registers
 // and neither the bottleneck's output nor the concat is written.
-template <bool TAIL>
+template <bool TAIL, bool SILU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_c32_kernel(const BneckArgs a) {
-    __shared__ __attribute__((aligned(16))) char xs[PATCH_BYTES];   // input patch, bf16 [pixel][32] at PITCH
-    __shared__ __attribute__((aligned(16))) char ts[PATCH_BYTES];   // act(conv1x1) of the patch, zero outside the image
+    // xs: input patch, bf16 [pixel][32] at PITCH; ts: act(conv1x1) of the patch, zero outside the image.  One array: the
+    // 1x1 stage's last pixel group reads 12 rows past xs, i.e. into ts (those results are dropped)
+    __shared__ __attribute__((aligned(16))) char smem[2 * PATCH_BYTES];
+    char* xs = smem;
+    char* ts = smem + PATCH_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, q = lane >> 4;
-    const bool silu = a.act == YDET_ACT_SILU;
     const float slope = a.act == YDET_ACT_LEAKY ? a.slope : 1.0f;   // ACT_NONE: leaky with slope 1
 
     // Weights as MFMA A operands, kept in registers for every tile of this workgroup.  A row r of fragment i is output
@@ -92,9 +100,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; ++e) b3v[i][e] = a.b3[(i >> 1) * 32 + q * 8 + (i & 1) * 4 + e];
         }
     }
-
-    // the rows behind the last patch pixel (read by the last 1x1 group) stay zero
-    for (int i = NPIX * PITCH + tid * 16; i < PATCH_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(xs + i) = uint4{0, 0, 0, 0};
 
     // input patch pieces of a tile: thread-private registers, fetched one tile ahead
     uint4 pre[NLOAD];
@@ -139,10 +144,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bf16x8 t;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                t[e] = (__bf16)(in ? act_fn(acc0[e] + b1v[0][e], silu, slope) : 0.f);
-                t[4 + e] = (__bf16)(in ? act_fn(acc1[e] + b1v[1][e], silu, slope) : 0.f);
+                const float v0 = act_fn<SILU>(acc0[e] + b1v[0][e], slope), v1 = act_fn<SILU>(acc1[e] + b1v[1][e], slope);
+                t[e] = (__bf16)(in ? v0 : 0.f);
+                t[4 + e] = (__bf16)(in ? v1 : 0.f);
             }
-            *reinterpret_cast<bf16x8*>(ts + p * PITCH + q * 16) = t;
+            if (p < NPIX) *reinterpret_cast<bf16x8*>(ts + p * PITCH + q * 16) = t;
         }
         __syncthreads();
         // ---- 3x3 over ts, + residual, -> y: a wave owns two output rows, i.e. four groups of 16 pixels ----------
@@ -165,13 +171,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t][0], tb, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t][1], tb, acc1, 0, 0, 0);
             }
-            bf16x8 res;
-            if (a.add) res = *reinterpret_cast<const bf16x8*>(xs + ((row + 1) * PW + col0 + 1 + px) * PITCH + q * 16);
+            // (the shortcut is a select, not a branch: the spot in xs is readable either way)
+            const bf16x8 res = *reinterpret_cast<const bf16x8*>(xs + ((row + 1) * PW + col0 + 1 + px) * PITCH + q * 16);
+            const bool add = a.add != 0;
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v0 = act_fn(acc0[e] + b2v[0][e], silu, slope), v1 = act_fn(acc1[e] + b2v[1][e], silu, slope);
-                if (a.add) { v0 += (float)res[e]; v1 += (float)res[4 + e]; }
+                float v0 = act_fn<SILU>(acc0[e] + b2v[0][e], slope), v1 = act_fn<SILU>(acc1[e] + b2v[1][e], slope);
+                v0 = add ? v0 + (float)res[e] : v0;
+                v1 = add ? v1 + (float)res[4 + e] : v1;
                 o[e] = (__bf16)v0;
                 o[4 + e] = (__bf16)v1;
             }
@@ -191,8 +199,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     bf16x8 o3;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o3[e] = (__bf16)act_fn(acc3[2 * h][e] + b3v[2 * h][e], silu, slope);
-                        o3[4 + e] = (__bf16)act_fn(acc3[2 * h + 1][e] + b3v[2 * h + 1][e], silu, slope);
+                        o3[e] = (__bf16)act_fn<SILU>(acc3[2 * h][e] + b3v[2 * h][e], slope);
+                        o3[4 + e] = (__bf16)act_fn<SILU>(acc3[2 * h + 1][e] + b3v[2 * h + 1][e], slope);
                     }
                     if (inside) *reinterpret_cast<bf16x8*>(yrow + (h * 32 + q * 8) * 2) = o3;
                 }
@@ -206,20 +214,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ---- 64 channels throughout -----------------------------------------------------------------------------------------
 // Same scheme for the 64-channel bottlenecks (the second C3 stage of YOLOv5s at 80 x 80), where the weights no longer
 // fit one wave's registers: the four waves split the OUTPUT CHANNELS (16 each: 18 A fragments of the 3x3 stage and 2
-// of the 1x1 stage per lane) and every wave walks all pixel groups of an 8 x 16 output tile.  Patches at a 144-byte
-// pixel pitch (128 of data + 16: eight consecutive pixels' 16-byte reads cover all banks once).  The finished tile
+// of the 1x1 stage per lane) and every wave walks all pixel groups of an 8 x 16 output tile.  Patches at a 160-byte
+// pixel pitch (128 of data + 32: the sixteen 16-byte slots (10 * pixel + chunk) mod 16 of a ds_read_b128 lane group are
+// all different; at 144 bytes seven of every eight collided).  The finished tile
 // goes through LDS once more so that global stores are 16-byte pieces of whole pixels.
 namespace c64 {
 constexpr int TH = 8, TW = 16;
 constexpr int PH = TH + 2, PW = TW + 2;
 constexpr int NPIX = PH * PW;                   // 180 patch pixels
 constexpr int NGRP = (NPIX + 15) / 16;          // 12 groups for the 1x1 stage (the last one reads 12 rows of slack)
-constexpr int PITCH = 144;
+constexpr int PITCH = 160;
 constexpr int PATCH_BYTES = NPIX * PITCH;       // 25920
 constexpr int SLACK = (NGRP * 16 - NPIX) * PITCH;
 constexpr int NLOAD = (NPIX * 8 + 255) / 256;   // 16-byte pieces of the input patch per thread
 }  // namespace c64
 
+template <bool SILU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bottleneck_c64_kernel(const BneckArgs a) {
     constexpr int TH = c64::TH, TW = c64::TW, PW = c64::PW, NPIX = c64::NPIX, NGRP = c64::NGRP, PITCH = c64::PITCH;
     constexpr int PATCH_BYTES = c64::PATCH_BYTES, SLACK = c64::SLACK, NLOAD = c64::NLOAD;
@@ -231,7 +241,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, q = lane >> 4;
-    const bool silu = a.act == YDET_ACT_SILU;
     const float slope = a.act == YDET_ACT_LEAKY ? a.slope : 1.0f;
 
     // A fragments of this wave's 16 output channels: row r = lane & 15 is channel 16 * wave + r, k chunk q
@@ -306,7 +315,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bool in = p < NPIX && (unsigned)(oy0 - 1 + pr) < (unsigned)a.H && (unsigned)(ox0 - 1 + pc) < (unsigned)a.W;
                 bf16x4 t;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = (__bf16)(in ? act_fn(acc[u][e] + b1v[e], silu, slope) : 0.f);
+                for (int e = 0; e < 4; ++e) {
+                    const float v = act_fn<SILU>(acc[u][e] + b1v[e], slope);
+                    t[e] = (__bf16)(in ? v : 0.f);
+                }
                 if (p < NPIX) *reinterpret_cast<bf16x4*>(ts + p * PITCH + co_d * 2) = t;
             }
         }
@@ -334,12 +346,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int u = 0; u < 4; ++u) {
                 const int row = gs + u;
                 char* spot = xs + ((row + 1) * PW + 1 + px) * PITCH + co_d * 2;
-                bf16x4 res, o;
-                if (a.add) res = *reinterpret_cast<const bf16x4*>(spot);
+                const bf16x4 res = *reinterpret_cast<const bf16x4*>(spot);
+                const bool add = a.add != 0;
+                bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = act_fn(acc[u][e] + b2v[e], silu, slope);
-                    if (a.add) v += (float)res[e];
+                    float v = act_fn<SILU>(acc[u][e] + b2v[e], slope);
+                    v = add ? v + (float)res[e] : v;
                     o[e] = (__bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(spot) = o;
@@ -431,9 +444,18 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, c
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     const long long grid = n_tiles < 2LL * cus ? n_tiles : 2LL * cus;
-    if (C == 32 && c3) hipLaunchKernelGGL(bottleneck_c32_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, a);
-    else if (C == 32) hipLaunchKernelGGL(bottleneck_c32_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(bottleneck_c64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    const bool silu = a.act == YDET_ACT_SILU;
+    const dim3 g((unsigned)grid), b(256);
+    if (C == 32 && c3) {
+        if (silu) hipLaunchKernelGGL((bottleneck_c32_kernel<true, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((bottleneck_c32_kernel<true, false>), g, b, 0, stream, a);
+    } else if (C == 32) {
+        if (silu) hipLaunchKernelGGL((bottleneck_c32_kernel<false, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((bottleneck_c32_kernel<false, false>), g, b, 0, stream, a);
+    } else {
+        if (silu) hipLaunchKernelGGL(bottleneck_c64_kernel<true>, g, b, 0, stream, a);
+        else hipLaunchKernelGGL(bottleneck_c64_kernel<false>, g, b, 0, stream, a);
+    }
     YDET_CHECK_LAUNCH("bottleneck kernel");
     return YDET_OK;
 }
