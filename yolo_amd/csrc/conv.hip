@@ -6,7 +6,7 @@
 //   co = output channel                                  -> the MFMA row
 //   k  = (kh*KW + kw)*Cin + c, gathered on the fly from the NHWC input (never materialised).
 // Channels sit on the MFMA row so that every lane ends up with 4 consecutive output channels of
-// one pixel: the epilogue stores 8 B (bf16) / 16 B (fp32) per lane straight into the NHWC output.
+// one pixel per fragment: the epilogue stores 16-byte pieces straight into the NHWC output.
 //
 // Both operands are K-contiguous (packed weights [Cout][K], NHWC input), so one K-step of a tile is
 // a set of 64-byte rows = 4 chunks of 16 B: 32 bf16 or 16 fp32 values.  The same staging code, LDS
@@ -24,8 +24,8 @@
 //                       precomputed pointer + a per-tap validity bit.  Tiles go global -> LDS directly
 //                       (LDS-DMA, global_load_lds_dwordx4; padded taps read a zero page) through a 3-stage
 //                       ring with two tiles in flight behind a counted vmcnt and one raw barrier per K-step.
-//                       The output tile leaves through LDS so that every store is a full 16-byte piece of a
-//                       contiguous channel run.
+//                       Weight rows are staged in an order that leaves every lane with whole 16-byte pieces of
+//                       its pixels' output rows, which it stores straight from registers.
 //   conv_generic_kernel any Cin that is a multiple of the chunk: per-thread tap tracking, global ->
 //                       registers -> LDS, two stages.
 #include <math.h>
@@ -388,8 +388,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Waves per SIMD the register allocation must leave room for: the eight-wave tile runs two workgroups per CU (its
+// LDS ring allows exactly two), the 128 x 128 four-wave tile three.
+constexpr int conv_dma_min_waves(int bn, int bm, int nw, bool head) {
+    return head ? 1 : nw == 8 ? 4 : (nw == 4 && bn == 128 && bm == 128) ? 3 : 1;
+}
+
 template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool HEAD = false>
-__global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
+__global__ __launch_bounds__(64 * WARPS_N * WARPS_M, conv_dma_min_waves(BN, BM, WARPS_N * WARPS_M, HEAD))
+void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     constexpr int NW = WARPS_N * WARPS_M;         // waves per workgroup (4 or 8)
     constexpr int NT = 64 * NW;
     static_assert(NW == 4 || NW == 8 || NW == 16, "four, eight or sixteen waves per workgroup");
@@ -403,10 +410,6 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     constexpr int LPT = WJ + XJ;                  // LDS-DMA instructions per wave and tile
     constexpr int STAGE = (WROWS + BM) * 64;
     constexpr int NSTAGE = 3;
-    constexpr int ROWB = BN * (int)sizeof(TOUT) + 16;  // epilogue row pitch (pad: spreads the 8-byte writes over banks)
-    constexpr int NPASS = (BM * ROWB + NSTAGE * STAGE - 1) / (NSTAGE * STAGE);
-    constexpr int PM = BM / NPASS;                     // pixels per epilogue pass
-    static_assert(BM % NPASS == 0 && (PM % WM == 0 || WM % PM == 0), "epilogue pass split");
     using frag_t = typename Frag<TIN>::type;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -444,10 +447,23 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
     // (l&3) ^ F[(l>>4)&3] (the swizzle lives on the source address, the LDS image stays lane-linear).
     const int srow = lane >> 2;
     const int lchunk = (lane & 3) ^ chunk_swz(lane >> 4);
+    // Which output channel sits on which row of the weight image is free.  With bf16 outputs row (i, r) of a wave's WN
+    // rows (fragment i, MFMA row r = 4 q + e) takes channel 32 (i>>1) + 8 q + 4 (i&1) + e: the accumulator rows a lane
+    // ends up with in fragments 2 s and 2 s + 1 are then EIGHT CONSECUTIVE channels (one 16-byte piece), and the four
+    // lane groups q of a pixel hold 64 consecutive bytes of it, so the epilogue stores straight from registers.  fp32
+    // outputs keep the natural order (a fragment's four rows are a 16-byte piece already), so does the decoding head.
+    constexpr bool PERM = !HEAD && sizeof(TOUT) == 2;
     const char* wsrc[WJ];
 #pragma unroll
-    for (int j = 0; j < WJ; ++j)
-        wsrc[j] = a.w + ((size_t)(n0 + (j * NW + wave) * 16 + srow) * a.kp + lchunk * EPC) * sizeof(TIN);
+    for (int j = 0; j < WJ; ++j) {
+        const int R = (j * NW + wave) * 16 + srow;
+        int ch = R;
+        if (PERM && R < BN) {
+            const int i = (R % WN) >> 4, r = R & 15;
+            ch = (R / WN) * WN + 32 * (i >> 1) + 8 * (r >> 2) + 4 * (i & 1) + (r & 3);
+        }
+        wsrc[j] = a.w + ((size_t)(n0 + ch) * a.kp + lchunk * EPC) * sizeof(TIN);
+    }
 
     YDET_STAMP(23);
     const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
@@ -561,17 +577,18 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 
     // weights of a 1x1 follower (see below): requested now, so that their latency runs under the K loop
     constexpr bool PW_OK = WARPS_N == 1 && BN == 64 && !HEAD && sizeof(TIN) == 2;
-    bf16x4 pw_lo[PW_OK ? 4 : 1][2], pw_hi[PW_OK ? 4 : 1][2];
+    // (rows in the same permuted order as the first convolution's, so the finished tile again holds 16-byte pieces per
+    // lane; the channels a lane holds for K step s are 32 s + 8 q .. + 7, the natural k order of a fragment)
+    bf16x8 pw_a[PW_OK ? 4 : 1][2];
     if constexpr (PW_OK) {
         if (a.pw_w) {
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
-                const char* wrow = a.pw_w + (size_t)(i2 * 16 + (lane & 15)) * a.pw_kp * 2;
+                const int r = lane & 15;
+                const char* wrow = a.pw_w + (size_t)(32 * (i2 >> 1) + 8 * (r >> 2) + 4 * (i2 & 1) + (r & 3)) * a.pw_kp * 2;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    pw_lo[i2][s2] = *reinterpret_cast<const bf16x4*>(wrow + (32 * s2 + 4 * (lane >> 4)) * 2);
-                    pw_hi[i2][s2] = *reinterpret_cast<const bf16x4*>(wrow + (32 * s2 + 16 + 4 * (lane >> 4)) * 2);
-                }
+                for (int s2 = 0; s2 < 2; ++s2)
+                    pw_a[i2][s2] = *reinterpret_cast<const bf16x8*>(wrow + (32 * s2 + 8 * (lane >> 4)) * 2);
             }
         }
     }
@@ -616,28 +633,37 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 
     // ---- optional 1x1 follower on the tile in registers ------------------------------------------------------
     // A wave of the 64-channel tile holds every channel of its pixels.  Finished (bias, activation, bf16) the values a
-    // lane holds for one pixel -- channels 16 i + 4 q .. + 3 of fragments i = 2 s, 2 s + 1 -- are taken as the eight
-    // k values of B fragment s; the A fragments of the second convolution are loaded with their columns in that same
-    // order (two 8-byte pieces per lane), so the second GEMM needs no LDS pass and the first map never leaves the chip.
+    // lane holds for one pixel -- channels 32 s + 8 q .. + 7, from fragments i = 2 s and 2 s + 1 --
+    // are taken as the eight k values of B fragment s; the A fragments of the second convolution are loaded with their
+    // columns in that same order (one 16-byte piece per lane), so the second GEMM needs no LDS pass and the first map
+    // never leaves the chip.
     if constexpr (WARPS_N == 1 && BN == 64 && !HEAD && sizeof(TIN) == 2) {
         if (a.pw_w) {
             const int q_ = lane >> 4;
             const bool silu1 = a.act == YDET_ACT_SILU;
             bf16x8 bfr[2][FM];
+            // (the activation is chosen once, outside the 32 values a lane finishes: chosen per value it compiled to a
+            // branch around each of them)
+            auto first_stage = [&](auto silu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 b1 = *reinterpret_cast<const float4*>(a.pw_b1 + i * 16 + q_ * 4);
-                const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+                for (int i = 0; i < 4; ++i) {
+                    const float4 b1 = *reinterpret_cast<const float4*>(a.pw_b1 + 32 * (i >> 1) + 8 * q_ + 4 * (i & 1));
+                    const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                for (int j = 0; j < FM; ++j)
+                    for (int j = 0; j < FM; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][e] + bb[e];
-                        x = silu1 ? x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f))
-                                  : (x > 0.f ? x : x * a.slope);
-                        bfr[i >> 1][j][(i & 1) * 4 + e] = (__bf16)x;
-                    }
-            }
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[i][j][e] + bb[e];
+                            if constexpr (decltype(silu)::value)
+                                x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+                            else
+                                x = x > 0.f ? x : x * a.slope;
+                            bfr[i >> 1][j][(i & 1) * 4 + e] = (__bf16)x;
+                        }
+                }
+            };
+            if (silu1) first_stage(std::true_type{});
+            else first_stage(std::false_type{});
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -645,12 +671,9 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 a2 = {pw_lo[i2][s2][0], pw_lo[i2][s2][1], pw_lo[i2][s2][2], pw_lo[i2][s2][3],
-                                       pw_hi[i2][s2][0], pw_hi[i2][s2][1], pw_hi[i2][s2][2], pw_hi[i2][s2][3]};
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int j = 0; j < FM; ++j) acc[i2][j] = mma(a2, bfr[s2][j], acc[i2][j]);
-                }
+                    for (int j = 0; j < FM; ++j) acc[i2][j] = mma(pw_a[i2][s2], bfr[s2][j], acc[i2][j]);
         }
     }
 
@@ -838,79 +861,74 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
         YDET_STAMP(25);
         return;
     }
+    // The values a lane holds for a pixel are whole 16-byte pieces of the output row (see PERM above): they leave
+    // straight from registers, no pass through LDS.  Piece p of a lane: CP channels from chan(p) on, out of fragments
+    // 2 p and 2 p + 1 (bf16 outputs) or fragment p (fp32 outputs).
+    constexpr int CP = PERM ? 8 : 4;                  // channels per piece
+    constexpr int NP = PERM ? FN / 2 : FN;            // pieces per lane and pixel
+    static_assert(!PERM || FN % 2 == 0, "bf16 pieces pair up fragments");
+    auto chan = [&](int p) { return wn * WN + (PERM ? 32 * p + 8 * q : 16 * p + 4 * q); };
     if (a.lds_epilogue) {
       with_epilogue_mode(a, [&](auto mode) {
         constexpr int MODE = decltype(mode)::value;
-        {
-            constexpr int V = 16 / (int)sizeof(TOUT);       // channels per 16-byte piece
-            constexpr int PIECES = BN / V;                  // pieces per pixel row of the tile
+        constexpr bool NORES = MODE >= 0 && (MODE & 8) != 0;
+        YDET_STAMP(20);
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                __builtin_amdgcn_s_barrier();               // the ring / the previous pass is no longer read
-                asm volatile("" ::: "memory");
-                YDET_STAMP(20);
-                // bf16 residuals of the pass are fetched up front (one memory latency for all of them instead of one
-                // per four values); fp32 residuals would double the accumulator registers and stay inline
-                constexpr bool NORES = MODE >= 0 && (MODE & 8) != 0;
-                constexpr bool PREFETCH_RES = sizeof(TIN) == 2 && !NORES;
-                bf16x4 rr[PREFETCH_RES ? FM : 1][PREFETCH_RES ? FN : 1];
-                if constexpr (PREFETCH_RES) {
-                    if (a.res) {
+        for (int j = 0; j < FM; ++j) {
+            const long long m = m0 + wm * WM + j * 16 + px;
+            const bool okm = m < a.M;
+            const long long mm = okm ? m : 0;
+            // residual pieces of this pixel, requested before the first value is finished
+            float r[NP][CP];
 #pragma unroll
-                        for (int j = 0; j < FM; ++j) {
-                            const int pl = wm * WM + j * 16 + px;
-                            if (pl / PM != pass) continue;
-                            const long long m = m0 + pl;
-                            const char* rrow = a.res + ((size_t)(m < a.M ? m : 0) * a.res_ld + a.res_coff) * sizeof(TIN);
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-                            for (int i = 0; i < FN; ++i) {
-                                const int co = n0 + wn * WN + i * 16 + q * 4;
-                                rr[j][i] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                                if (m < a.M && co < a.Cout) rr[j][i] = *reinterpret_cast<const bf16x4*>(rrow + (size_t)co * sizeof(TIN));
+                for (int c = 0; c < CP; ++c) r[p][c] = 0.f;
+            if constexpr (!NORES) {
+                if (a.res) {
+                    const char* rrow = a.res + ((size_t)mm * a.res_ld + a.res_coff + n0) * sizeof(TIN);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        if (okm && n0 + chan(p) < a.Cout) {
+                            if constexpr (sizeof(TIN) == 2 && CP == 8) {
+                                const bf16x8 t = *reinterpret_cast<const bf16x8*>(rrow + chan(p) * 2);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) r[p][e] = (float)t[e];
+                            } else {
+                                load4<TIN>(rrow + (size_t)chan(p) * sizeof(TIN), r[p]);
                             }
                         }
                     }
                 }
+            }
 #pragma unroll
-                for (int j = 0; j < FM; ++j) {
-                    const int pl = wm * WM + j * 16 + px;   // pixel inside the tile
-                    if (pl / PM != pass) continue;
-                    const long long m = m0 + pl;
-                    const char* rrow = (!NORES && a.res && m < a.M) ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
-                    char* lrow = smem + (pl - pass * PM) * ROWB;
+            for (int p = 0; p < NP; ++p) {
+                const int cl = chan(p);
+                float o[CP];
 #pragma unroll
-                    for (int i = 0; i < FN; ++i) {
-                        const int cl = wn * WN + i * 16 + q * 4;   // channel inside the tile
-                        const int co = n0 + cl;
-                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                        float r[4] = {0.f, 0.f, 0.f, 0.f};
-                        if constexpr (PREFETCH_RES) {
-                            if (a.res) { r[0] = (float)rr[j][i][0]; r[1] = (float)rr[j][i][1]; r[2] = (float)rr[j][i][2]; r[3] = (float)rr[j][i][3]; }
-                        } else if constexpr (!NORES) {
-                            if (rrow && co < a.Cout) load4<TIN>(rrow + (size_t)co * sizeof(TIN), r);
-                        }
-                        finish4<MODE>(v, r, cst + cl, cst + BN + cl, cst + 2 * BN + cl, a);
-                        store4<TOUT>(lrow + cl * sizeof(TOUT), v);
-                    }
+                for (int hf = 0; hf < CP / 4; ++hf) {
+                    const int i = PERM ? 2 * p + hf : p;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    const float r4[4] = {r[p][4 * hf], r[p][4 * hf + 1], r[p][4 * hf + 2], r[p][4 * hf + 3]};
+                    finish4<MODE>(v, r4, cst + cl + 4 * hf, cst + BN + cl + 4 * hf, cst + 2 * BN + cl + 4 * hf, a);
+                    o[4 * hf] = v[0]; o[4 * hf + 1] = v[1]; o[4 * hf + 2] = v[2]; o[4 * hf + 3] = v[3];
                 }
-                YDET_STAMP(21);
-                __syncthreads();
-                YDET_STAMP(29);
-                for (int idx = tid; idx < PM * PIECES; idx += NT) {
-                    const int pl = idx / PIECES, piece = idx - pl * PIECES;
-                    const long long m = m0 + pass * PM + pl;
-                    const int co = n0 + piece * V;
-                    if (m < a.M && co < a.cout_store) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + pl * ROWB + piece * 16);
-                        // channels from y_split on belong to the second destination
-                        char* dst = co >= a.y_split ? a.y2 + ((size_t)m * a.y2_ld + a.y2_coff + (co - a.y_split)) * sizeof(TOUT)
-                                                    : a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT);
-                        *reinterpret_cast<u32x4*>(dst) = v;
-                    }
+                const int co = n0 + cl;
+                if (!okm || co >= a.cout_store) continue;
+                // channels from y_split on belong to the second destination
+                char* dst = co >= a.y_split ? a.y2 + ((size_t)m * a.y2_ld + a.y2_coff + (co - a.y_split)) * sizeof(TOUT)
+                                            : a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT);
+                if constexpr (PERM) {
+                    bf16x8 t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (__bf16)o[e];
+                    *reinterpret_cast<bf16x8*>(dst) = t;
+                } else {
+                    store4<TOUT>(dst, o);
                 }
             }
-            YDET_STAMP(30);
         }
+        YDET_STAMP(30);
       });
       return;
     }
@@ -924,7 +942,7 @@ __global__ __launch_bounds__(64 * WARPS_N * WARPS_M) void conv_dma_kernel(const 
             const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
-                const int cl = wn * WN + i * 16 + q * 4;
+                const int cl = wn * WN + (PERM ? 32 * (i >> 1) + 8 * q + 4 * (i & 1) : 16 * i + 4 * q);
                 const int co = n0 + cl;
                 if (co >= a.Cout) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
@@ -955,8 +973,10 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
         constexpr int NW = WARPS_N * WARPS_M;
         constexpr int WROWS = BN < 16 * NW ? 16 * NW : BN;
         const size_t lds_dma = 3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float);
+        // 16-byte pieces straight from registers: output (and residual) slices must be 16-byte aligned
         a.lds_epilogue = (a.y_ld % (16 / (int)sizeof(TOUT)) == 0 && a.y_coff % (16 / (int)sizeof(TOUT)) == 0 &&
-                          a.cout_store % (16 / (int)sizeof(TOUT)) == 0)
+                          a.cout_store % (16 / (int)sizeof(TOUT)) == 0 &&
+                          (!a.res || (a.res_ld % (16 / (int)sizeof(TIN)) == 0 && a.res_coff % (16 / (int)sizeof(TIN)) == 0)))
                              ? 1
                              : 0;
         if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
