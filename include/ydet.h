@@ -290,6 +290,42 @@ int ydet_nms_v5_static(const float* pred, int N, int nboxes, int no, float conf_
                        const uint8_t* class_mask, const float* row_max, float* out_det, int32_t* out_count,
                        void* stream);
 
+/* non_max_suppression2: yolov5_official/utils.py:318-460.  pred [N, nboxes, 5+nc] fp32 as for ydet_nms_v5.
+ * Candidates: obj > conf_thres (:336), 2 < w, h < 4096 (:339), cls*obj > conf_thres for every class (multi_cls, or
+ * conf_thres < 0.01, :352-359) or for the first-maximum class only (:360-362); descending score (:371; equal scores:
+ * lower box first).  Per class the first 500 rows (:390-391) go through `method`:
+ *   YDET_NMS2_HARD_BATCH / YDET_NMS2_HARD  torchvision's rule (suppress IoU > nms_thres), :377 / :395; the batch form
+ *                          offsets boxes by class * (largest coordinate + 1) and has no 500-row limit: a class with
+ *                          more than 2048 candidates sets *overflow
+ *   YDET_NMS2_HARD_MYSELF  :398-405 (keep bbox_iou2 < nms_thres)      YDET_NMS2_DIOU  :447-454 (DIoU instead)
+ *   YDET_NMS2_AND          :408-413 (a head needs a neighbour with IoU > 0.5)
+ *   YDET_NMS2_MERGE        :416-425 (score-weighted mean of the head's cluster; nms_thres must be below 1)
+ *   YDET_NMS2_SOFT         :428-444 (scores decay by exp(-iou^2 / 0.5), rows at or below conf_thres leave)
+ * Output per image: out_rows [N, out_cap, 6] = (x1, y1, x2, y2, score, cls) in descending score order (:456-458),
+ * out_count [N] rows valid (an image without detections has 0 rows where the reference leaves None); out_cap >=
+ * ydet_nms2_out_cap(no, method) holds every case.  *overflow (device int32) is set non-zero when one (image, class)
+ * list could not hold its candidates (more than 2048 scores inside one histogram bin): the result is then incomplete. */
+enum { YDET_NMS2_HARD_BATCH = 0, YDET_NMS2_HARD = 1, YDET_NMS2_HARD_MYSELF = 2, YDET_NMS2_AND = 3, YDET_NMS2_MERGE = 4,
+       YDET_NMS2_SOFT = 5, YDET_NMS2_DIOU = 6 };
+size_t ydet_nms2_workspace_bytes(int N, int nboxes, int no, int method);
+int ydet_nms2_out_cap(int no, int method);
+int ydet_nms2(const float* pred, int N, int nboxes, int no, float conf_thres, float nms_thres, int multi_cls,
+              int method, float* out_rows, int out_cap, int32_t* out_count, int32_t* overflow, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* diou_non_max_suppression: yolov5_official/utils.py:463-548 (Cluster-Weighted DIoU-NMS, the alternative the author
+ * toggles at yolov5_official/val.py:89-90).  Candidates as in non_max_suppression with multi_label = (nc > 1) (:475),
+ * optional class filter (:505-506), descending score, the first max_box (<= 2048) of an image (:521-523); their
+ * pairwise jaccard_diou (:210-244) on boxes offset by class * 4096 (agnostic: no offset), upper triangle; the
+ * row-masking iteration of :528-535 (at most 200 rounds); keep = column maximum <= iou_thres (:536); coordinates
+ * replaced by the score-weighted mean over the entries above 0.8 of each row (:538-543).
+ * out_rows [N, max_box, 6]: the kept rows of every image in slot order, out_count [N]; like the reference the result
+ * includes one row (NaN box, score 0, class 0) per unused slot.  iou_thres must be positive. */
+size_t ydet_nms_cluster_diou_workspace_bytes(int N, int nboxes, int no, int max_box);
+int ydet_nms_cluster_diou(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                          int max_box, int agnostic, const uint8_t* class_mask, float* out_rows, int32_t* out_count,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* postprocess + nms: utils/utils.py:101-133 and :15-42.
  * boxes [N, n, 4], scores [N, n, nc] fp32.  Per image: cls = argmax (first maximum),
  * score = max, candidates have score >= conf_thresh; per class greedy NMS in descending score

@@ -259,6 +259,98 @@ def test_box_iou(golden):
     np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=1e-6, atol=1e-7)
 
 
+# ---- the alternative NMS flavours (yolov5_official/utils.py:318-548) ---------------------------------------------------
+NMS2_EXACT = ("hard_nms_batch", "hard_nms", "hard_nms_myself", "and", "diou_nms")
+
+
+def _check_nms2(pred, kw, method, expect):
+    from yolo_amd.yolov5_official.utils import non_max_suppression2
+    out = non_max_suppression2(torch.as_tensor(pred).to(DEV), method=method, **kw)
+    assert len(out) == len(expect)
+    for i, (o, ref) in enumerate(zip(out, expect)):
+        ref = np.zeros((0, 6), np.float32) if ref is None else ref
+        if o is None:
+            assert len(ref) == 0, (method, i)
+            continue
+        o = o.cpu().numpy()
+        assert o.shape == ref.shape, (method, i, o.shape, ref.shape)
+        assert (np.diff(o[:, 4]) <= 0).all(), "rows must come in descending score order"
+        if method != "merge":
+            # the order among (nearly) equal scores is the sort's own in the reference (torch.argsort, unstable): rows
+            # are compared as a set, keyed by class and box
+            o = o[np.lexsort((o[:, 3], o[:, 2], o[:, 1], o[:, 0], o[:, 5]))]
+            ref = ref[np.lexsort((ref[:, 3], ref[:, 2], ref[:, 1], ref[:, 0], ref[:, 5]))]
+        if method in NMS2_EXACT:
+            np.testing.assert_array_equal(o, ref, err_msg=f"{method} image {i}")
+        else:   # 'merge': summation order of the weighted mean; 'soft_nms': exp on the device
+            np.testing.assert_array_equal(o[:, 5], ref[:, 5])
+            np.testing.assert_allclose(o, ref, rtol=3e-6, atol=1e-4 if method == "merge" else 1e-6, err_msg=f"{method} image {i}")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("method", list(O.NMS2_METHODS))
+def test_nms2_golden(golden, tag, method):
+    """ydet_nms2 against the outputs of the reference's non_max_suppression2 (fixtures G12): rows, order, scores and
+    classes bit-exact; coordinates of 'merge' and scores of 'soft_nms' to 3e-6."""
+    g = golden(f"g12_nms2_{tag}")
+    kw = json.loads(str(g["kw"]))
+    n = g["pred"].shape[0]
+    _check_nms2(g["pred"], kw, method, [g[f"{method}_{i}"] for i in range(n)])
+
+
+@pytest.mark.parametrize("method", ["hard_nms_myself", "diou_nms", "soft_nms", "and", "merge", "hard_nms_batch"])
+def test_nms2_full_size_against_oracle(method):
+    """25200 boxes x 80 classes: classes with more than 500 candidates (the 500-row limit), empty images, and the
+    multi-class expansion at conf 0.001; the oracle is fed the same tensor."""
+    pred = clustered_predictions(2, 25200, 80, seed=31, obj_pass=0.04)
+    pred[1, :, 4] = 0.0                               # an image without candidates
+    conf = 0.2 if method == "hard_nms_batch" else 0.02
+    kw = dict(conf_thres=conf, nms_thres=0.5, multi_cls=True)
+    _check_nms2(pred, kw, method, O.non_max_suppression2(pred.numpy(), method=method, **kw))
+
+
+def test_nms2_edge_cases():
+    from yolo_amd.yolov5_official.utils import non_max_suppression2
+    pred = clustered_predictions(1, 64, 3, seed=5, img_size=64.0)
+    one = pred.clone()
+    one[0, 1:, 4] = 0.0                               # a single box: every method returns it untouched (:387-389)
+    for method in O.NMS2_METHODS:
+        _check_nms2(one, dict(conf_thres=0.01, nms_thres=0.5, multi_cls=False), method,
+                    O.non_max_suppression2(one.numpy(), 0.01, 0.5, False, method))
+    tiny = pred.clone()
+    tiny[0, :, 2:4] = 1.5                             # every box below the 2-pixel limit (:339)
+    assert non_max_suppression2(tiny.to(DEV), 0.01, 0.5)[0] is None
+    with pytest.raises(ValueError):
+        non_max_suppression2(pred.to(DEV), method="nope")
+    with pytest.raises(RuntimeError):
+        non_max_suppression2(pred, 0.01, 0.5)         # CPU tensor: there is no CPU path
+
+
+def _check_cluster(pred, kw, expect):
+    from yolo_amd.yolov5_official.utils import diou_non_max_suppression
+    out = diou_non_max_suppression(torch.as_tensor(pred).to(DEV), **kw)
+    for i, (o, ref) in enumerate(zip(out, expect)):
+        o = o.cpu().numpy()
+        assert o.shape == ref.shape, (i, o.shape, ref.shape)
+        np.testing.assert_array_equal(o[:, 4:], ref[:, 4:])                       # kept slots: scores and classes exact
+        np.testing.assert_array_equal(np.isnan(o), np.isnan(ref))                 # padding rows carry NaN boxes
+        np.testing.assert_allclose(np.nan_to_num(o[:, :4]), np.nan_to_num(ref[:, :4]), rtol=3e-6, atol=2e-4)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_cluster_diou_nms_golden(golden, tag):
+    """ydet_nms_cluster_diou against the reference's diou_non_max_suppression (fixtures G12)."""
+    g = golden(f"g12_diou_{tag}")
+    kw = json.loads(str(g["kw"]))
+    _check_cluster(g["pred"], kw, [g[f"out{i}"] for i in range(g["pred"].shape[0])])
+
+
+def test_cluster_diou_nms_full_size_against_oracle():
+    pred = clustered_predictions(2, 25200, 80, seed=33, obj_pass=0.05)
+    kw = dict(conf_thres=0.1, iou_thres=0.6, max_box=1500)
+    _check_cluster(pred, kw, O.diou_non_max_suppression(pred.numpy(), **kw))
+
+
 # ---- pooling / resampling / layout against torch fp32 ------------------------------------------------------------
 def _run_graph(build, *xs, compute="fp32"):
     g = engine.Graph(DEV, compute)

@@ -240,3 +240,41 @@ def test_preproc_geometry_and_pixels_golden(golden):
     for i in range(int(g["n_bt"])):
         x = OP.base_transform(g[f"bt{i}_img"], int(g[f"bt{i}_size"]), g[f"bt{i}_mean"], g[f"bt{i}_std"])
         np.testing.assert_array_equal(x, g[f"bt{i}_out"])
+
+
+# ---- the alternative NMS flavours (yolov5_official/utils.py:318-548) ---------------------------------------------------
+NMS2_EXACT = ("hard_nms_batch", "hard_nms", "hard_nms_myself", "and", "diou_nms")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_non_max_suppression2_golden(golden, tag):
+    """Every method of non_max_suppression2 against the reference's outputs: selections, order, scores and classes
+    exact; 'merge' coordinates (a masked sum whose order torch leaves open) and 'soft_nms' scores (exp) to 1e-6."""
+    g = golden(f"g12_nms2_{tag}")
+    kw = json.loads(str(g["kw"]))
+    for method in O.NMS2_METHODS:
+        out = O.non_max_suppression2(g["pred"], method=method, **kw)
+        for i, o in enumerate(out):
+            ref = g[f"{method}_{i}"]
+            o = np.zeros((0, 6), np.float32) if o is None else o
+            assert o.shape == ref.shape, (method, i)
+            if method in NMS2_EXACT:
+                np.testing.assert_array_equal(o, ref, err_msg=f"{method} {i}")
+            else:
+                np.testing.assert_array_equal(o[:, 5], ref[:, 5])
+                np.testing.assert_allclose(o, ref, rtol=2e-6, atol=1e-6, err_msg=f"{method} {i}")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_diou_non_max_suppression_golden(golden, tag):
+    """Cluster-Weighted DIoU-NMS: kept slots, scores and classes exact (padding rows included: NaN box, zero score);
+    the weighted coordinates to 1e-6 relative (a matmul whose summation order is the library's)."""
+    g = golden(f"g12_diou_{tag}")
+    kw = json.loads(str(g["kw"]))
+    out = O.diou_non_max_suppression(g["pred"], **kw)
+    for i, o in enumerate(out):
+        ref = g[f"out{i}"]
+        assert o.shape == ref.shape
+        np.testing.assert_array_equal(o[:, 4:], ref[:, 4:])
+        np.testing.assert_array_equal(np.isnan(o), np.isnan(ref))
+        np.testing.assert_allclose(np.nan_to_num(o[:, :4]), np.nan_to_num(ref[:, :4]), rtol=2e-6, atol=1e-4)

@@ -249,6 +249,39 @@ def main():
         arrs["n_calls"] = len(calls)
         save(f"g4_nms_{tag}", **arrs)
 
+    # ================= G12: the alternative NMS flavours (yolov5_official/utils.py:318-548) ============
+    # torchvision.ops.boxes.{nms, batched_nms} are absent like torchvision.ops.nms above: the published greedy rule
+    # (oracle.postproc.torchvision_nms; batched = the same on boxes offset by class * (max coordinate + 1)) stands in,
+    # so the 'hard_nms' / 'hard_nms_batch' methods are pinned only up to that call.
+    def _tv_nms(boxes, scores, thr):
+        return torch.from_numpy(O.torchvision_nms(boxes.numpy(), scores.numpy(), float(thr)))
+
+    def _tv_batched(boxes, scores, idxs, thr):
+        off = idxs.to(boxes) * (boxes.max() + 1)
+        return _tv_nms(boxes + off[:, None], scores, thr)
+
+    rutils.torchvision.ops.boxes = types.SimpleNamespace(nms=_tv_nms, batched_nms=_tv_batched)
+    g12 = [("a", clustered_predictions(3, 600, 6, seed=11, img_size=320.0), dict(conf_thres=0.1, nms_thres=0.5, multi_cls=True)),
+           ("b", clustered_predictions(2, 900, 3, seed=12, img_size=320.0, obj_pass=0.6), dict(conf_thres=0.3, nms_thres=0.6, multi_cls=False)),
+           ("c", clustered_predictions(2, 4000, 2, seed=13, clusters=6, obj_pass=0.9), dict(conf_thres=0.05, nms_thres=0.45, multi_cls=True))]
+    for tag, pred, kw in g12:
+        arrs = {"pred": pred.numpy(), "kw": np.array(json.dumps(kw))}
+        for method in ["hard_nms_batch", "hard_nms", "hard_nms_myself", "and", "merge", "soft_nms", "diou_nms"]:
+            before = pred.clone()
+            out = rutils.non_max_suppression2(pred, method=method, **kw)
+            assert torch.equal(before, pred), "reference mutated its input"
+            for i, o in enumerate(out):
+                arrs[f"{method}_{i}"] = np.zeros((0, 6), np.float32) if o is None else o.numpy()
+        save(f"g12_nms2_{tag}", **arrs)
+    for tag, pred, kw in [("a", clustered_predictions(3, 500, 4, seed=21, img_size=320.0), dict(conf_thres=0.1, iou_thres=0.6, max_box=256)),
+                          ("b", clustered_predictions(2, 2500, 1, seed=22, clusters=12, obj_pass=0.8), dict(conf_thres=0.2, iou_thres=0.5, max_box=1500)),
+                          ("c", clustered_predictions(2, 400, 3, seed=23, img_size=320.0), dict(conf_thres=0.1, iou_thres=0.45, max_box=200, agnostic=True, classes=[0, 2]))]:
+        out = rutils.diou_non_max_suppression(pred.clone(), **kw)
+        arrs = {"pred": pred.numpy(), "kw": np.array(json.dumps(kw))}
+        for i, o in enumerate(out):
+            arrs[f"out{i}"] = o.numpy()
+        save(f"g12_diou_{tag}", **arrs)
+
     # ================= G5: blocks on tiny tensors (fp32) ==============================================
     def block_case(tag, block, x, eps=None):
         init_deterministic(block, seed=5)

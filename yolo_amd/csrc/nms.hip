@@ -912,6 +912,68 @@ extern "C" int ydet_nms_v5(const float* pred, int N, int nboxes, int no, float c
                       row_max, out_det, out_count, workspace, workspace_bytes, stream);
 }
 
+// ---- Cluster-Weighted DIoU-NMS (yolov5_official/utils.py:463-548): the same candidate selection, another ending ------
+namespace ydet {
+struct ClusterArgs {
+    const float4* sbox; const u64* sorted; const unsigned* ns; const float* pred;
+    int N, nboxes, no, nc, stride, max_box;
+    float thr;
+    u64* ge; u64* gt; float* out; int32_t* out_count;
+};
+size_t cluster_diou_ws_bytes(int N, int max_box);
+int launch_cluster_diou(ClusterArgs a, void* ws, hipStream_t stream);
+}  // namespace ydet
+
+extern "C" size_t ydet_nms_cluster_diou_workspace_bytes(int N, int nboxes, int no, int max_box) {
+    (void)no;
+    if (N <= 0 || nboxes <= 0 || max_box <= 0) return 0;
+    return v5_ws_layout(N, nboxes, nullptr, nullptr, nullptr, nullptr, nullptr) + cluster_diou_ws_bytes(N, max_box);
+}
+
+extern "C" int ydet_nms_cluster_diou(const float* pred, int N, int nboxes, int no, float conf_thres, float iou_thres,
+                                     int max_box, int agnostic, const uint8_t* class_mask, float* out_rows,
+                                     int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream) {
+    clear_error();
+    YDET_CHECK_ARG(pred && out_rows && out_count && workspace, "nms_cluster_diou: null pointer");
+    YDET_CHECK_ARG(N > 0 && N <= 65535 && nboxes > 0 && no >= 6 && no <= kTileFloats, "nms_cluster_diou: N=%d nboxes=%d no=%d", N, nboxes, no);
+    YDET_CHECK_ARG(max_box >= 1 && max_box <= 2048, "nms_cluster_diou: max_box=%d (1..2048)", max_box);
+    YDET_CHECK_ARG(iou_thres > 0.f, "nms_cluster_diou: iou_thres must be positive");
+    YDET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)pred & 3) == 0, "nms_cluster_diou: alignment");
+    const int nc = no - 5;
+    YDET_CHECK_ARG((long long)nboxes * nc < 0xFFFFFFFFLL, "nms_cluster_diou: nboxes*nc does not fit 32 bits");
+    size_t oh, om, ol, os, ob;
+    const size_t base = v5_ws_layout(N, nboxes, &oh, &om, &ol, &os, &ob);
+    const size_t need = base + cluster_diou_ws_bytes(N, max_box);
+    if (workspace_bytes < need) return fail(YDET_ERR_WORKSPACE, "nms_cluster_diou: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    char* ws = (char*)workspace;
+    V5Args a;
+    a.pred = pred; a.N = N; a.nboxes = nboxes; a.no = no; a.nc = nc;
+    a.rows_per_block = kTileFloats / no;
+    if (a.rows_per_block > 128) a.rows_per_block = 128;
+    a.scan_rows = kScanTile / no < kScanRows ? kScanTile / no : kScanRows;
+    a.conf = conf_thres; a.iou = iou_thres;
+    a.multi = nc > 1 ? 1 : 0;                                     // :475 overrides the argument
+    a.agnostic = agnostic ? 1 : 0;
+    a.max_nms = max_box; a.max_det = max_box; a.max_wh = 4096.f; a.class_mask = class_mask;
+    a.base16 = f2key_host(conf_thres) >> 16;
+    a.row_max_ws = (float*)(ws + oh); a.meta = (V5Meta*)(ws + om); a.list = (u64*)(ws + ol);
+    a.row_max = a.row_max_ws;
+    a.sorted = (u64*)(ws + os); a.sbox = (float4*)(ws + ob);
+    a.out_det = nullptr; a.out_count = nullptr;
+    const dim3 grid2((unsigned)((nboxes + a.scan_rows - 1) / a.scan_rows), (unsigned)N);
+    hipLaunchKernelGGL(v5_rowmax_kernel, grid2, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_pick_kernel, dim3((unsigned)N), dim3(kPickThreads), 0, s, a);
+    hipLaunchKernelGGL(v5_exact_select_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(v5_rank_kernel, dim3((unsigned)N), dim3(256), 0, s, a);
+    YDET_CHECK_LAUNCH("nms_cluster_diou selection kernels");
+    ydet::ClusterArgs c;
+    c.sbox = a.sbox; c.sorted = a.sorted; c.ns = reinterpret_cast<const unsigned*>(a.meta); c.pred = pred;
+    c.N = N; c.nboxes = nboxes; c.no = no; c.nc = nc; c.stride = kMaxNms; c.max_box = max_box;
+    c.thr = iou_thres; c.ge = nullptr; c.gt = nullptr; c.out = out_rows; c.out_count = out_count;
+    return ydet::launch_cluster_diou(c, ws + base, s);
+}
+
 // ---- the same operator for callers that must not allocate ---------------------------------------------------------
 // The workspace of ydet_nms_v5 (row maxima, per-image records, candidate list, sorted keys and boxes) lives in a
 // device array that is part of the library's code object: every GPU the library runs on holds its own copy until the

@@ -132,6 +132,63 @@ def nms_v5(pred, conf_thres=0.25, iou_thres=0.45, multi_label=False, agnostic=Fa
     return det, count
 
 
+NMS2_METHODS = {"hard_nms_batch": 0, "hard_nms": 1, "hard_nms_myself": 2, "and": 3, "merge": 4, "soft_nms": 5, "diou_nms": 6}
+
+
+def nms2(pred, conf_thres=0.25, nms_thres=0.6, multi_cls=True, method="diou_nms"):
+    """pred [N, nboxes, 5+nc] fp32 CUDA -> (rows [N, cap, 6], count [N] int32, overflow [1] int32) on the device:
+    yolov5_official/utils.py:318-460, rows (x1, y1, x2, y2, score, cls) in descending score order."""
+    _need_cuda(pred)
+    if method not in NMS2_METHODS:
+        raise ValueError(f"unknown NMS method {method!r}")
+    if method == "merge" and not nms_thres < 1.0:
+        raise ValueError("merge needs nms_thres < 1 (the reference does not terminate otherwise)")
+    lib = _ffi.lib()
+    pred = pred.float().contiguous()
+    N, nboxes, no = pred.shape
+    dev = pred.device
+    m = NMS2_METHODS[method]
+    cap = min(lib.ydet_nms2_out_cap(no, m), max(nboxes * (no - 5), 1))
+    rows = torch.empty(N, cap, 6, device=dev, dtype=torch.float32)
+    count = torch.zeros(N, device=dev, dtype=torch.int32)
+    overflow = torch.zeros(1, device=dev, dtype=torch.int32)
+    if N == 0 or nboxes == 0:
+        return rows, count, overflow
+    ws_bytes = lib.ydet_nms2_workspace_bytes(N, nboxes, no, m)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _ffi.check(lib.ydet_nms2(pred.data_ptr(), N, nboxes, no, float(conf_thres), float(nms_thres), int(bool(multi_cls)), m,
+                                 rows.data_ptr(), cap, count.data_ptr(), overflow.data_ptr(), ws.data_ptr(), ws_bytes,
+                                 _ffi.current_stream()), "ydet_nms2")
+    return rows, count, overflow
+
+
+def nms_cluster_diou(pred, conf_thres=0.1, iou_thres=0.6, max_box=1500, classes=None, agnostic=False):
+    """pred [N, nboxes, 5+nc] fp32 CUDA -> (rows [N, max_box, 6], count [N] int32): yolov5_official/utils.py:463-548."""
+    _need_cuda(pred)
+    lib = _ffi.lib()
+    pred = pred.float().contiguous()
+    N, nboxes, no = pred.shape
+    dev = pred.device
+    rows = torch.empty(N, max_box, 6, device=dev, dtype=torch.float32)
+    count = torch.zeros(N, device=dev, dtype=torch.int32)
+    if N == 0:
+        return rows, count
+    mask_ptr = None
+    if classes:
+        m = torch.zeros(no - 5, dtype=torch.uint8)
+        m[torch.as_tensor(list(classes), dtype=torch.long)] = 1
+        mask = m.to(dev)
+        mask_ptr = mask.data_ptr()
+    ws_bytes = lib.ydet_nms_cluster_diou_workspace_bytes(N, nboxes, no, max_box)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _ffi.check(lib.ydet_nms_cluster_diou(pred.data_ptr(), N, nboxes, no, float(conf_thres), float(iou_thres), int(max_box),
+                                             int(bool(agnostic)), mask_ptr, rows.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                             ws_bytes, _ffi.current_stream()), "ydet_nms_cluster_diou")
+    return rows, count
+
+
 def nms_perclass(boxes, scores, conf_thresh, nms_thresh):
     """boxes [N, n, 4], scores [N, n, nc] fp32 CUDA.
     Returns (keep [N, n] uint8, cls [N, n] int32, best [N, n] fp32): utils/utils.py:101-133."""

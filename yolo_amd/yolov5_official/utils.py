@@ -96,6 +96,30 @@ def non_max_suppression_padded(prediction, conf_thres=0.25, iou_thres=0.45, clas
                       max_nms=max_det, max_wh=4096.0, classes=classes)
 
 
+def non_max_suppression2(prediction, conf_thres=0.25, nms_thres=0.6, multi_cls=True, method='diou_nms'):
+    """Reference :318-460: per-class NMS by `method` ('hard_nms_batch', 'hard_nms', 'hard_nms_myself', 'and', 'merge',
+    'soft_nms', 'diou_nms').  Returns, per image, None (nothing passed the filters) or a [k, 6] tensor (xyxy, score,
+    cls) in descending score; the work is done by ydet_nms2 on the GPU."""
+    if not prediction.is_cuda:
+        raise RuntimeError("non_max_suppression2 runs on the GPU only: pass a CUDA prediction tensor")
+    rows, count, overflow = ops.nms2(prediction, conf_thres, nms_thres, multi_cls, method)
+    counts = count.tolist() + overflow.tolist()      # the one device->host sync
+    if counts[-1]:
+        raise RuntimeError("non_max_suppression2: a class holds more tied / unlimited candidates than the GPU lists (2048)")
+    return [rows[i, :c] if c else None for i, c in enumerate(counts[:-1])]
+
+
+def diou_non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, max_box=1500, classes=None, agnostic=False,
+                             use_gpu=False, max_det=300, labels=None, multi_label=True):
+    """Reference :463-548 (Cluster-Weighted DIoU-NMS; `use_gpu`, `max_det`, `labels` and `multi_label` are accepted and
+    unused there too: multi-label is forced by nc > 1).  Returns per image the kept rows of its max_box slots -- like
+    the reference, unused slots come back as rows with a NaN box and zero score.  Runs ydet_nms_cluster_diou."""
+    if not prediction.is_cuda:
+        raise RuntimeError("diou_non_max_suppression runs on the GPU only: pass a CUDA prediction tensor")
+    rows, count = ops.nms_cluster_diou(prediction, conf_thres, iou_thres, max_box, classes, agnostic)
+    return [rows[i, :c] for i, c in enumerate(count.tolist())]
+
+
 def _append_apriori_labels(prediction, labels):
     """Autolabelling rows (reference :138-144): each label becomes a box with obj = cls = 1 placed after
     the image's own boxes; images are padded with all-zero rows, which never pass the obj test."""
