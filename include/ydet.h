@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 11
+#define YDET_ABI_VERSION 12
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -117,6 +117,14 @@ typedef struct {
     const void* pw_w;
     const float* pw_bias;
     int32_t pw_cout, pw_kp;
+    /* Grouped and dilated convolutions (nn.Conv2d(groups=g, dilation=d): utils/moduleUtils.py:9-13 `g`, `d`;
+     * yolov5_official/modules.py:19-21 DWConv, :208-218 Bottleneck(g=)).  groups > 1: output channel co belongs to
+     * group co / (Cout / groups) and reads the cin_group = (real input channels) / groups input channels from
+     * group * cin_group on; weights are packed [cout_pad][kp] with k = (kh*KW + kw)*cin_group + c.  dilation > 1:
+     * tap (kh, kw) reads input pixel (ho*stride - pad + kh*dilation, ...), Ho = (H + 2 pad - dilation (KH-1) - 1) /
+     * stride + 1.  Either one sends the launch to a direct (non-MFMA) kernel; y2, x_up, pw_w and cout_store are then
+     * not available.  0 means 1 (cin_group: Cin / groups). */
+    int32_t groups, dilation, cin_group;
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 

@@ -473,6 +473,69 @@ def test_conv_against_torch(compute, tol, case):
         assert engine.conv_kernel_label(Cin, Cout, k, k, p, _ffi.BF16, _ffi.BF16, M=N * Ho * Wo).startswith("conv_dma<128x256")
 
 
+GROUPED_CASES = [
+    # N, H, W, Cin, Cout, k, s, p, groups, dilation, act, residual
+    (2, 20, 20, 64, 64, 3, 1, 1, 64, 1, "silu", None),       # depthwise (DWConv, yolov5_official/modules.py:19-21)
+    (2, 21, 19, 32, 64, 3, 2, 1, 32, 1, "silu", None),       # depthwise with a channel multiplier, stride 2, odd sizes
+    (1, 16, 16, 32, 64, 3, 1, 1, 2, 1, "silu", "after"),     # Bottleneck(g=2).cv2 with its shortcut (:208-218)
+    (2, 12, 12, 48, 24, 1, 1, 0, 3, 1, "leaky", None),       # grouped 1x1
+    (1, 18, 18, 16, 32, 3, 1, 2, 1, 2, "leaky", None),       # dilated (utils/moduleUtils.py:9-13 `d`)
+    (1, 17, 15, 32, 32, 3, 2, 3, 4, 3, "none", "before"),    # grouped and dilated, stride 2
+]
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("case", GROUPED_CASES)
+def test_conv_grouped_dilated_against_torch(compute, tol, case):
+    """nn.Conv2d(groups=, dilation=) through the direct kernel, against torch fp32."""
+    N, H, W, Cin, Cout, k, s, p, groups, dil, act, resk = case
+    g = _gen(9, f"gconv{case}")
+    conv = nn.Conv2d(Cin, Cout, k, s, p, dilation=dil, groups=groups, bias=True)
+    bn = nn.BatchNorm2d(Cout) if act != "none" else None
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (Cin // groups * k * k)) ** 0.5)
+        conv.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        if bn is not None:
+            bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+            bn.eval()
+    x = torch.randn(N, Cin, H, W, generator=g)
+    with torch.no_grad():
+        y = conv(x)
+        if bn is not None:
+            y = bn(y)
+    r = torch.randn(y.shape, generator=g) if resk else None
+    actf = {"silu": F.silu, "leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t}[act]
+    ref = actf(y + r) if resk == "before" else (actf(y) + (r if resk else 0))
+    code = {"silu": _ffi.ACT_SILU, "leaky": _ffi.ACT_LEAKY, "none": _ffi.ACT_NONE}[act]
+
+    def build(gr, ins):
+        mode = {None: _ffi.RES_NONE, "after": _ffi.RES_AFTER_ACT, "before": _ffi.RES_BEFORE_ACT}[resk]
+        out = gr.conv(ins[0], conv, bn, act=code, slope=0.1, res=ins[1] if resk else None, res_mode=mode,
+                      out_dtype=_ffi.F32 if act == "none" else None)
+        gr.to_nchw(out, "y")
+
+    out = _run_graph(build, *([x, r] if resk else [x]), compute=compute)
+    assert out["y"].shape == ref.shape
+    assert rel_err(out["y"].float().cpu(), ref) < tol
+
+
+def test_grouped_modules_lower():
+    """DWConv and Bottleneck(g=2) of the YOLOv5 mirrors run on the GPU path and match their own torch forward."""
+    from yolo_amd.yolov5_official.modules import Bottleneck, DWConv
+    from yolo_amd.synthetic import init_deterministic
+    for name, mod, cin in (("dw", DWConv(32, 64, 3, 2), 32), ("bott", Bottleneck(64, 64, True, g=2), 64)):
+        init_deterministic(mod, seed=3)
+        mod.eval()
+        x = torch.randn(2, cin, 24, 20, generator=_gen(4, name))
+        with torch.no_grad():
+            ref = mod(x)
+        out = _run_graph(lambda gr, ins: gr.to_nchw(mod.lower(gr, ins[0]), "y"), x, compute="fp32")
+        assert rel_err(out["y"].float().cpu(), ref) < 1e-3, name
+
+
 def test_conv_argument_validation():
     lib = _ffi.lib()
     d = _ffi.ConvDesc()

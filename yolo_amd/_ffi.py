@@ -15,7 +15,7 @@ RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
  OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK, OP_C3_TAIL, OP_RGB_CONV) = range(14)
 MAX_ANCHORS = 8
-ABI_VERSION = 11   # YDET_ABI_VERSION of include/ydet.h these structs were written against
+ABI_VERSION = 12   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("y2", C.c_void_p), ("y2_ld", C.c_int32), ("y2_coff", C.c_int32), ("y_split", C.c_int32),
         ("x_up", C.c_void_p), ("x_up_ld", C.c_int32), ("x_up_coff", C.c_int32), ("x_up_C", C.c_int32),
         ("pw_w", C.c_void_p), ("pw_bias", C.c_void_p), ("pw_cout", C.c_int32), ("pw_kp", C.c_int32),
+        ("groups", C.c_int32), ("dilation", C.c_int32), ("cin_group", C.c_int32),
     ]
 
 

@@ -376,6 +376,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, const ydet_conv_desc* c3, hipStream_t stream) {
     using namespace ydet;
     YDET_CHECK_ARG(c1 && c2, "bottleneck_fused: null descriptor");
+    YDET_CHECK_ARG(c1->groups <= 1 && c1->dilation <= 1 && c2->groups <= 1 && c2->dilation <= 1 &&
+                       (!c3 || (c3->groups <= 1 && c3->dilation <= 1)), "bottleneck_fused: plain convolutions (one group, no dilation)");
     YDET_CHECK_ARG(c1->x && c1->w && c1->bias && c2->w && c2->bias && (c2->y || c3), "bottleneck_fused: null x/w/bias/y pointer");
     YDET_CHECK_ARG(c1->in_dtype == YDET_BF16 && c1->out_dtype == YDET_BF16 && c2->in_dtype == YDET_BF16 &&
                        c2->out_dtype == YDET_BF16, "bottleneck_fused: bf16 only");

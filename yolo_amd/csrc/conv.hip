@@ -808,6 +808,59 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     }
 }
 
+// Grouped and / or dilated convolutions (nn.Conv2d(groups=, dilation=); DWConv and Bottleneck(g=) of
+// yolov5_official/modules.py:19-21, :208-218; `d`, `g` of utils/moduleUtils.py:9-13): one thread per (pixel, output
+// channel), channels fastest so that stores and the depthwise reads are contiguous; fp32 accumulation in tap-major,
+// channel-minor order.  Such layers carry a small share of a network's work (a depthwise 3x3 is 9 MACs per output);
+// the MFMA kernels stay reserved for dense convolutions.
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a) {
+    const long long total = a.M * (long long)a.cout_store;
+    const int HoWo = a.Ho * a.Wo, cpg = a.Cout / a.groups;
+    const TIN* X = reinterpret_cast<const TIN*>(a.x);
+    const TIN* Wt = reinterpret_cast<const TIN*>(a.w);
+    for (long long gid = (long long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long long)gridDim.x * 256) {
+        const long long m = gid / a.cout_store;
+        const int co = (int)(gid - m * a.cout_store);
+        float v = 0.f;
+        if (co < a.Cout) {
+            const int n = (int)(m / HoWo), rem = (int)(m - (long long)n * HoWo);
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int c_first = (co / cpg) * a.cin_group;
+            const TIN* wrow = Wt + (size_t)co * a.kp;
+            for (int kh = 0; kh < a.KH; ++kh) {
+                const int hi = ho * a.stride - a.pad + kh * a.dilation;
+                if ((unsigned)hi >= (unsigned)a.H) continue;
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    const int wi = wo * a.stride - a.pad + kw * a.dilation;
+                    if ((unsigned)wi >= (unsigned)a.W) continue;
+                    const TIN* xp = X + ((size_t)((long long)n * a.H + hi) * a.W + wi) * a.x_ld + a.x_coff + c_first;
+                    const TIN* wp = wrow + (kh * a.KW + kw) * a.cin_group;
+                    for (int c = 0; c < a.cin_group; ++c) v += to_f32(xp[c]) * to_f32(wp[c]);
+                }
+            }
+            if (a.bias) v += a.bias[co];
+            float r = 0.f;
+            if (a.res) r = to_f32(reinterpret_cast<const TIN*>(a.res)[(size_t)m * a.res_ld + a.res_coff + co]);
+            if (a.res_mode == YDET_RES_BEFORE_ACT) v += r;
+            v = a.act == YDET_ACT_SILU ? activate(v, YDET_ACT_SILU, 0.f) : (v > 0.f ? v : v * a.slope);
+            if (a.res_mode == YDET_RES_AFTER_ACT) v += r;
+            if (a.post_scale) v = activate(v * a.post_scale[co] + a.post_shift[co], a.post_act, a.post_slope);
+        }
+        reinterpret_cast<TOUT*>(a.y)[(size_t)m * a.y_ld + a.y_coff + co] = from_f32<TOUT>(v);
+    }
+}
+
+template <typename TIN, typename TOUT>
+int launch_direct(const ConvArgs& a, hipStream_t stream) {
+    const long long total = a.M * (long long)a.cout_store;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;       // grid-stride beyond 64 workgroups per CU
+    hipLaunchKernelGGL((conv_direct_kernel<TIN, TOUT>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    YDET_CHECK_LAUNCH("conv_direct_kernel");
+    return YDET_OK;
+}
+
 template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
 int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
@@ -878,6 +931,7 @@ static bool wide_tile_pays(long long M, int Cout, int K, bool dma_ok) {
 
 template <typename TIN, typename TOUT>
 int launch_dtype(const ConvArgs& a, hipStream_t stream) {
+    if (a.groups > 1 || a.dilation > 1) return launch_direct<TIN, TOUT>(a, stream);
     // YDET_CONV_TILE=<channels>x<pixels> forces a tile shape (tuning aid)
     static const char* forced = getenv("YDET_CONV_TILE");
     if (forced) {
@@ -916,9 +970,18 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     const int bk = 4 * epc;
     YDET_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: empty shape");
     YDET_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv: bad kernel geometry");
-    YDET_CHECK_ARG(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 &&
-                       d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1 && d->Ho > 0 && d->Wo > 0,
-                   "conv: Ho/Wo (%d,%d) do not match H,W,k,s,p", d->Ho, d->Wo);
+    const int groups = d->groups > 0 ? d->groups : 1, dil = d->dilation > 0 ? d->dilation : 1;
+    const bool direct = groups > 1 || dil > 1;
+    YDET_CHECK_ARG(d->Ho == (d->H + 2 * d->pad - dil * (d->KH - 1) - 1) / d->stride + 1 &&
+                       d->Wo == (d->W + 2 * d->pad - dil * (d->KW - 1) - 1) / d->stride + 1 && d->Ho > 0 && d->Wo > 0,
+                   "conv: Ho/Wo (%d,%d) do not match H,W,k,s,p,d", d->Ho, d->Wo);
+    const int cin_group = direct ? (d->cin_group > 0 ? d->cin_group : d->Cin / groups) : d->Cin;
+    if (direct) {
+        YDET_CHECK_ARG(d->Cout % groups == 0 && cin_group >= 1 && (long long)cin_group * groups <= d->Cin,
+                       "conv: %d groups of %d input channels over Cin=%d, Cout=%d", groups, cin_group, d->Cin, d->Cout);
+        YDET_CHECK_ARG(d->y2 == nullptr && d->x_up == nullptr && d->pw_w == nullptr,
+                       "conv: a grouped / dilated convolution excludes y2, x_up and a 1x1 follower");
+    }
     YDET_CHECK_ARG(d->Cin % epc == 0 && d->x_ld % epc == 0 && d->x_coff % epc == 0,
                    "conv: Cin/x_ld/x_coff (%d,%d,%d) must be multiples of %d", d->Cin, d->x_ld, d->x_coff, epc);
     YDET_CHECK_ARG(d->x_coff >= 0 && d->x_coff + d->Cin <= d->x_ld, "conv: input slice exceeds x_ld");
@@ -945,8 +1008,8 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     YDET_CHECK_ARG(d->cout_store == 0 || (d->cout_store >= d->Cout && d->cout_store <= d->cout_pad &&
                                           d->y_coff + d->cout_store <= d->y_ld),
                    "conv: cout_store %d (need Cout <= cout_store <= cout_pad and inside y_ld)", d->cout_store);
-    YDET_CHECK_ARG(d->kp % bk == 0 && d->kp >= d->KH * d->KW * d->Cin, "conv: kp %d (need multiple of %d, >= %d)",
-                   d->kp, bk, d->KH * d->KW * d->Cin);
+    YDET_CHECK_ARG(d->kp % bk == 0 && d->kp >= d->KH * d->KW * cin_group, "conv: kp %d (need multiple of %d, >= %d)",
+                   d->kp, bk, d->KH * d->KW * cin_group);
     YDET_CHECK_ARG(d->cout_pad % 128 == 0 && d->cout_pad >= d->Cout, "conv: cout_pad %d", d->cout_pad);
     YDET_CHECK_ARG(d->act >= 0 && d->act <= 2 && d->res_mode >= 0 && d->res_mode <= 2, "conv: bad act/res_mode");
     YDET_CHECK_ARG((d->res != nullptr) == (d->res_mode != YDET_RES_NONE), "conv: res pointer vs res_mode");
@@ -982,6 +1045,7 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
         a.bias = d->pw_bias; a.Cout = d->pw_cout; a.cout_store = d->pw_cout;
         a.vec_store = (d->pw_cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0) ? 1 : 0;
     }
+    a.groups = groups; a.dilation = dil; a.cin_group = cin_group;
     a.x_up = nullptr; a.up_ld = 0; a.up_coff = 0; a.up_C = 0;
     if (d->x_up) {
         YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H % 2 == 0 && d->W % 2 == 0,
@@ -1036,6 +1100,7 @@ int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, h
     const int rc = fill_conv_args(d, a);
     if (rc != YDET_OK) return rc;
     YDET_CHECK_ARG(hd != nullptr && hd->z != nullptr, "head_conv_decode: null head descriptor / z");
+    YDET_CHECK_ARG(a.groups == 1 && a.dilation == 1, "head_conv_decode: a plain convolution (one group, no dilation)");
     const int bk = d->in_dtype == YDET_BF16 ? 32 : 16;
     YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % bk == 0,
                    "head_conv_decode: a 1x1 convolution with Cin a multiple of %d", bk);

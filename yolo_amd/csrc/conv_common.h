@@ -35,6 +35,7 @@ struct ConvArgs {
     const char* pw_w; // a 1x1 convolution run on the finished tile in registers (64-channel tile only): its weights
     const float* pw_b1;   // [cout_pad][pw_kp]; pw_b1 = bias of the FIRST convolution (a.bias is then the second's), or null
     int pw_kp;
+    int groups, dilation, cin_group;   // direct kernel only (groups > 1 or dilation > 1)
     const char* x_up; // pointwise convs only: input channels [0, up_C) are read from this map of half the size at
     int up_ld, up_coff, up_C;   // (h/2, w/2) -- a nearest-neighbour 2x upsample that is never materialised; 0: none
 };

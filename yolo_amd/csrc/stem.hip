@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void rgb_conv3x3_kernel(const StemArgs a) {
 
 int ydet_launch_rgb_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {
     YDET_CHECK_ARG(d != nullptr && d->x && d->w && d->y, "rgb_conv3x3: null pointer");
+    YDET_CHECK_ARG(d->groups <= 1 && d->dilation <= 1, "rgb_conv3x3: a plain convolution (one group, no dilation)");
     YDET_CHECK_ARG(dtype_ok(x_dtype), "rgb_conv3x3: bad image dtype");
     YDET_CHECK_ARG(d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "rgb_conv3x3: bf16 weights and output only");
     YDET_CHECK_ARG(d->N > 0 && d->N <= 65535 && d->H > 0 && d->W > 0, "rgb_conv3x3: image %d x %d x %d", d->N, d->H, d->W);
@@ -340,6 +341,7 @@ namespace {
 
 int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {
     YDET_CHECK_ARG(d != nullptr && d->x && d->w && d->y, "focus_conv: null pointer");
+    YDET_CHECK_ARG(d->groups <= 1 && d->dilation <= 1, "focus_conv: a plain convolution (one group, no dilation)");
     YDET_CHECK_ARG(dtype_ok(x_dtype) || x_dtype == YDET_U8, "focus_conv: bad image dtype");
     YDET_CHECK_ARG(d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "focus_conv: bf16 weights and output only");
     YDET_CHECK_ARG(d->N > 0 && d->N <= 65535 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0,

@@ -66,19 +66,24 @@ class T:
 class PackedConv:
     """Device-resident packed weights + bias of one (conv [+ BatchNorm]) for one input layout."""
 
-    def __init__(self, w, b, Cin, Cout, KH, KW, kp, cout_pad, cin_real=None):
+    def __init__(self, w, b, Cin, Cout, KH, KW, kp, cout_pad, cin_real=None, groups=1, dilation=1):
         self.w, self.b, self.Cin, self.Cout, self.KH, self.KW, self.kp, self.cout_pad = w, b, Cin, Cout, KH, KW, kp, cout_pad
-        self.cin_real = cin_real or Cin
+        self.cin_real = cin_real or Cin      # input channels one output channel reads (per group)
+        self.groups, self.dilation = groups, dilation
+
+    @property
+    def plain(self):
+        """One group, no dilation: the shapes the MFMA kernels and every fusion pass handle."""
+        return self.groups == 1 and self.dilation == 1
 
 
 def fold_conv(conv, bn=None, bn_slice=None, device=None):
-    """(w [Cout, KH, KW, Cin] fp32, b [Cout] fp32) of `conv` with `bn` (optionally the channel range `bn_slice` of a
+    """(w [Cout, KH, KW, Cin / groups] fp32, b [Cout] fp32) of `conv` with `bn` (optionally the channel range `bn_slice` of a
     wider BatchNorm) folded in: y = gamma * (conv(x) + bias - mean) / sqrt(var + eps) + beta, as nn.BatchNorm2d
     computes in eval mode."""
-    if conv.groups != 1 or tuple(conv.dilation) != (1, 1):
-        raise NotImplementedError("grouped / dilated convolutions are outside the accelerated path")
-    if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
-        raise NotImplementedError("only square kernels / strides / paddings are used by the reference models")
+    if (conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]
+            or conv.dilation[0] != conv.dilation[1]):
+        raise NotImplementedError("only square kernels / strides / paddings / dilations are used by the reference models")
     device = device or conv.weight.device
     w = conv.weight.detach().to(device=device, dtype=torch.float32)
     Cout = w.shape[0]
@@ -95,12 +100,15 @@ def fold_conv(conv, bn=None, bn_slice=None, device=None):
     return w.permute(0, 2, 3, 1), b
 
 
-def pack_folded(w, b, cin_phys=None, dtype=_ffi.BF16):
-    """Pack folded weights [Cout, KH, KW, Cin] + bias into the kernel's [cout_pad][kp] layout."""
+def pack_folded(w, b, cin_phys=None, dtype=_ffi.BF16, groups=1, dilation=1):
+    """Pack folded weights [Cout, KH, KW, Cin] + bias into the kernel's [cout_pad][kp] layout.  With groups > 1 the
+    last axis is the group's channels and is packed as it is (k = tap * cin_group + c)."""
     Cout, KH, KW, Cin = w.shape
-    cin_phys = cin_phys or Cin
     epc = 8 if dtype == _ffi.BF16 else 4
-    if cin_phys % epc:
+    if groups > 1:
+        cin_phys = Cin
+    cin_phys = cin_phys or Cin
+    if cin_phys % epc and groups == 1:
         raise ValueError(f"input channel count {cin_phys} must be a multiple of {epc}")
     if cin_phys > Cin:
         w = torch.nn.functional.pad(w, (0, cin_phys - Cin))
@@ -111,13 +119,19 @@ def pack_folded(w, b, cin_phys=None, dtype=_ffi.BF16):
     wp[:Cout, :K] = w.reshape(Cout, K)
     bp = torch.zeros(cout_pad, device=w.device, dtype=torch.float32)
     bp[:Cout] = b
-    return PackedConv(wp.to(_TORCH_DT[dtype]).contiguous(), bp, cin_phys, Cout, KH, KW, kp, cout_pad, cin_real=Cin)
+    return PackedConv(wp.to(_TORCH_DT[dtype]).contiguous(), bp, cin_phys, Cout, KH, KW, kp, cout_pad, cin_real=Cin,
+                      groups=groups, dilation=dilation)
 
 
 def pack_conv(conv, bn=None, bn_slice=None, cin_phys=None, dtype=_ffi.BF16, device=None):
     """Fold `bn` into `conv` and pack (see fold_conv / pack_folded)."""
     w, b = fold_conv(conv, bn, bn_slice, device)
-    return pack_folded(w, b, cin_phys, dtype)
+    return pack_folded(w, b, cin_phys, dtype, groups=conv.groups, dilation=conv.dilation[0])
+
+
+def is_plain(conv):
+    """nn.Conv2d with one group and no dilation."""
+    return conv.groups == 1 and tuple(conv.dilation) == (1, 1)
 
 
 class Graph:
@@ -179,6 +193,7 @@ class Graph:
         Returns (buffer, list of the pairs' channel slices in order); they share one storage.  With `separate` (two
         pairs, LDS-DMA kernel shapes only) each pair gets a storage of its own (the convolution's second destination)
         and the buffer returned is None."""
+        assert all(is_plain(c) for c, _ in pairs), "grouped / dilated convolutions are not merged with their siblings"
         folded = [fold_conv(c, b, None, self.device) for c, b in pairs]
         first = pairs[0][0]
         for c, _ in pairs[1:]:
@@ -228,9 +243,11 @@ class Graph:
             ps[:pc.Cout], pb[:pc.Cout] = scale, shift
             self.keep.append((ps, pb))
             post_rec = (ps, pb, pact, float(pslope))
-        s, p = conv.stride[0], conv.padding[0]
-        Ho = (x.H + 2 * p - pc.KH) // s + 1
-        Wo = (x.W + 2 * p - pc.KW) // s + 1
+        s, p, dil = conv.stride[0], conv.padding[0], pc.dilation
+        if pc.groups > 1:
+            assert x.C >= conv.in_channels and pc.cin_real * pc.groups == conv.in_channels
+        Ho = (x.H + 2 * p - dil * (pc.KH - 1) - 1) // s + 1
+        Wo = (x.W + 2 * p - dil * (pc.KW - 1) - 1) // s + 1
         if out is None:
             out = self.new(x.N, Ho, Wo, pc.Cout, dtype=out_dtype, external=external)
         assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, pc.Cout), "conv output shape mismatch"
@@ -238,7 +255,8 @@ class Graph:
             assert (res.N, res.H, res.W, res.C) == (out.N, out.H, out.W, out.C), "residual shape mismatch"
         self.ops.append(("conv", dict(x=x, y=out, res=res, pc=pc, stride=s, pad=p, act=act, slope=float(slope),
                                       res_mode=res_mode if res is not None else _ffi.RES_NONE, post=post_rec)))
-        self._tag_up(self.ops[-1][1])
+        if pc.plain:
+            self._tag_up(self.ops[-1][1])
         return out
 
     def bottleneck(self, x, cv1, cv2, act=_ffi.ACT_NONE, slope=0.0, add=True, out=None):
@@ -246,7 +264,7 @@ class Graph:
         activation.  One fused kernel when every channel count is 32 (or 64) on the bf16 path and `out` does not alias `x`
         (the intermediate map then never exists in HBM); otherwise two convolutions."""
         (c1, bn1), (c2, bn2) = cv1, cv2
-        geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups)
+        geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups if is_plain(c) else -1)
         Cc = x.C
         fused = (self.dt == _ffi.BF16 and Cc in (32, 64) and c1.out_channels == Cc and c2.out_channels == Cc
                  and geom(c1) == (1, 1, 0, 1) and geom(c2) == (3, 1, 1, 1) and x.dtype == _ffi.BF16
@@ -274,7 +292,7 @@ class Graph:
         and cv3 = (1x1 conv 64 -> 64, bn) with the same activation: neither the bottleneck's output nor the concat is
         written.  Returns None when the shapes do not qualify (the caller then lowers the pieces separately)."""
         (c1, bn1), (c2, bn2), (c3, bn3) = cv1, cv2, cv3
-        geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups)
+        geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups if is_plain(c) else -1)
         ok = (self.dt == _ffi.BF16 and x.C == 32 and other.C == 32 and x.dtype == _ffi.BF16 and other.dtype == _ffi.BF16
               and c1.out_channels == 32 and c2.out_channels == 32 and geom(c1) == (1, 1, 0, 1) and geom(c2) == (3, 1, 1, 1)
               and geom(c3) == (1, 1, 0, 1) and c3.in_channels == 64 and c3.out_channels == 64
@@ -445,7 +463,7 @@ class Graph:
                 continue
             pa, xa, ya = A["pc"], A["x"], A["y"]
             ra, oa = ya.resolve()
-            if not (pa.Cout == 64 and xa.C % 32 == 0 and pa.KH * pa.KW <= 32 and xa.dtype == _ffi.BF16 and ya.dtype == _ffi.BF16
+            if not (pa.plain and pa.Cout == 64 and xa.C % 32 == 0 and pa.KH * pa.KW <= 32 and xa.dtype == _ffi.BF16 and ya.dtype == _ffi.BF16
                     and not ra.external and ya.whole() and ra is ya.st and all(r is not ra for r in out_roots)):
                 continue
             readers = [(k2, a2) for k2, a2 in self.ops if a2 is not A and any(t.resolve()[0] is ra for t in inputs(k2, a2))]
@@ -453,7 +471,7 @@ class Graph:
                 continue
             B = readers[0][1]
             pb = B["pc"]
-            if not (B["x"].resolve() == (ra, oa) and B["x"].C == 64 and (pb.KH, pb.KW, B["stride"], B["pad"]) == (1, 1, 1, 0)
+            if not (pb.plain and B["x"].resolve() == (ra, oa) and B["x"].C == 64 and (pb.KH, pb.KW, B["stride"], B["pad"]) == (1, 1, 1, 0)
                     and 32 < pb.Cout <= 64 and pb.kp == 64 and B["y"].dtype == _ffi.BF16
                     and all(B.get(k) is None for k in ("res", "post", "up", "pre"))
                     and (B["act"], B["slope"]) == (A["act"], A["slope"])):
@@ -485,7 +503,7 @@ class Graph:
                 continue
             A = readers[0][1]
             pc, y = A["pc"], A["y"]
-            if not ((pc.KH, pc.KW, A["stride"], A["pad"]) == (3, 3, 1, 1) and pc.Cout % 8 == 0 and pc.Cout <= 64 and y.dtype == _ffi.BF16
+            if not (pc.plain and (pc.KH, pc.KW, A["stride"], A["pad"]) == (3, 3, 1, 1) and pc.Cout % 8 == 0 and pc.Cout <= 64 and y.dtype == _ffi.BF16
                     and all(A.get(k) is None for k in ("res", "post", "y2", "up", "pre")) and not y.resolve()[0].external):
                 continue
             cin = pc.Cin                                   # channels the weights were packed for (3 padded to the vector)
@@ -645,6 +663,7 @@ class Plan:
             assert rr.dtype == rx.dtype
             d.res, d.res_ld, d.res_coff = self._ptr(rr, arena, i, "cres", record), rr.ld, orr
         d.kp, d.cout_pad = pc.kp, pc.cout_pad
+        d.groups, d.dilation, d.cin_group = pc.groups, pc.dilation, (pc.cin_real if pc.groups > 1 else 0)
         d.act, d.slope, d.res_mode = a["act"], a["slope"], a["res_mode"]
         d.in_dtype, d.out_dtype = rx.dtype, ry.dtype
         if a.get("y2") is not None:
@@ -673,7 +692,7 @@ class Plan:
         # a stand-alone output buffer whose channel count is not a vector multiple (75 / 125 / 255-channel heads)
         # is stored with its zero pad channels, so that every store is a whole 16-byte piece
         vec = 4 if ry.dtype == _ffi.F32 else 8
-        if y.st is ry and y.coff == 0 and pc.Cout % vec and _round_up(pc.Cout, vec) <= min(ry.ld, pc.cout_pad):
+        if pc.plain and y.st is ry and y.coff == 0 and pc.Cout % vec and _round_up(pc.Cout, vec) <= min(ry.ld, pc.cout_pad):
             d.cout_store = _round_up(pc.Cout, vec)
 
     # ---- execution -------------------------------------------------------------------------------------
@@ -815,9 +834,11 @@ def _wide_tile_pays(M, cout, K):
     return r256 * (0.85 if K >= 256 else 1.0) < r128 - 0.02
 
 
-def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0):
+def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=True):
     """Name of the kernel instantiation ydet_conv2d_nhwc launches for this shape (mirrors launch_dtype() / launch_tile()
     in csrc/conv.hip), so that timings keyed by it line up with a profiler's per-symbol statistics."""
+    if not plain:
+        return "conv_direct"
     bn, bm = conv_tile(cout)
     bk = 32 if in_dt == _ffi.BF16 else 16
     dts = f"{'bf16' if in_dt == _ffi.BF16 else 'f32'}->{'bf16' if out_dt == _ffi.BF16 else 'f32'}"
@@ -856,7 +877,8 @@ def _op_info(kind, a):
             nbytes += y.N * y.H * y.W * y.C * esz(x)
         if a.get("up") is not None:     # the first C_up channels come from a map of a quarter of the pixels
             nbytes -= x.N * x.H * x.W * a["up"][1] * esz(x) * 3 // 4
-        return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W),
+        return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W,
+                                                         plain=pc.plain),
                     flops=flops,
                     bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
