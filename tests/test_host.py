@@ -293,6 +293,81 @@ def test_two_rank_gloo_exchange(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+VAL_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch
+from oracle import postproc as O
+from yolo_amd import distributed as yd
+from yolo_amd.synthetic import clustered_predictions
+from yolo_amd.yolov5_official import val as V
+
+rank, world, _ = yd.init_from_env("cpu")
+N_IMG, BS, NC = 10, 2, 4
+pred_all = clustered_predictions(N_IMG, 300, NC, seed=7, img_size=64.0, obj_pass=0.2)
+
+
+class FakeModel(torch.nn.Module):       # "forward" looks the decoded predictions up by the image index in pixel 0
+    names = [str(i) for i in range(NC)]
+    seen = []
+    def forward(self, img, augment=False):
+        idx = (img[:, 0, 0, 0] * 255.0).round().long()
+        FakeModel.seen += idx.tolist()
+        return pred_all[idx], None
+
+
+def cpu_nms_padded(pred, conf, iou, labels=(), multi_label=False, agnostic=False, max_det=300):   # the GPU operator's stand-in
+    out = O.non_max_suppression(pred.numpy(), conf, iou, multi_label=multi_label, agnostic=agnostic, max_det=max_det)
+    det = torch.zeros(len(out), max_det, 6); cnt = torch.zeros(len(out), dtype=torch.int32)
+    for i, o in enumerate(out):
+        det[i, :len(o)] = torch.from_numpy(o); cnt[i] = len(o)
+    return det, cnt
+
+
+V.non_max_suppression_padded = cpu_nms_padded
+g = torch.Generator().manual_seed(3)
+batches = []
+for b in range(N_IMG // BS):
+    img = torch.zeros(BS, 3, 64, 64, dtype=torch.uint8)
+    tg = []
+    for k in range(BS):
+        i = b * BS + k
+        img[k, :, 0, 0] = i
+        top = pred_all[i][pred_all[i][:, 4] > 0.5][:3]           # labels near some confident predictions
+        for r in top:
+            tg.append([k, float(r[5:].argmax()), *(r[:4] / 64.0).tolist()])
+    batches.append((img, torch.tensor(tg).reshape(-1, 6), [f"im{b}_{k}.jpg" for k in range(BS)], [((64, 64), ((1.0, 1.0), (0.0, 0.0)))] * BS))
+res, maps, _ = V.run(dict(nc=NC), model=FakeModel(), dataloader=batches, device="cpu", half=False, conf_thres=0.05, iou_thres=0.5)
+own = list(range(*[x * BS for x in yd.shard_range(len(batches), rank, world)]))
+assert FakeModel.seen == own, (FakeModel.seen, own)           # a rank runs only its contiguous range of images
+json.dump(dict(res=[float(v) for v in res], maps=[float(v) for v in maps]), open(os.path.join(sys.argv[2], f"val{rank}_{world}.json"), "w"))
+if world > 1:
+    torch.distributed.barrier(); torch.distributed.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_val_run_equals_one_process(tmp_path):
+    """val.run sharded over two gloo ranks (contiguous image ranges, one packed detection all-gather) returns the
+    metrics of the single-process run, on every rank."""
+    script = tmp_path / "val_worker.py"
+    script.write_text(VAL_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path)], capture_output=True, text=True, env=env, timeout=240)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29613", str(script), ROOT, str(tmp_path)],
+                        capture_output=True, text=True, env=dict(env, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613"), timeout=240)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    import json as _json
+    one = _json.load(open(tmp_path / "val0_1.json"))
+    assert one["res"][2] > 0.0, "the synthetic set must produce a non-trivial mAP"
+    for rank in (0, 1):
+        two = _json.load(open(tmp_path / f"val{rank}_2.json"))
+        assert two == one
+
+
 def test_results_file_rounding_without_strings():
     """The vectorised rounding equals the reference's write-then-parse round trip ('{:.3f}' score, '{:.1f}' of x + 1),
     including exact halves (x.25 -> half to even on the exact value)."""

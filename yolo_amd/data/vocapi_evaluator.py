@@ -242,7 +242,7 @@ class VOCAPIEvaluator:
             d[:, :4] *= torch.tensor([w, h, w, h], device=d.device, dtype=d.dtype)  # reference :68-69
             det[r, : d.shape[0]] = d
             cnt[r], ids[r] = d.shape[0], i
-        det, cnt, ids = ydist.all_gather_detections(det, cnt, ids)  # the one exchange step
+        det, cnt, ids = ydist.all_gather_detections(det, cnt, ids, total=n_img)  # the one exchange step: one collective, no size exchange
         det, cnt = det.cpu().numpy(), cnt.cpu().numpy()
         self.all_boxes = [[np.empty((0, 5), dtype=np.float32) for _ in range(n_img)] for _ in self.labelmap]
         for r, i in enumerate(ids.tolist()):

@@ -39,7 +39,8 @@ def shard_range(n, rank, world_size):
 
 def all_gather_rows(t):
     """Concatenate the rows (dim 0) of `t` from every rank, in rank order; row counts may differ.
-    One all-reduce(MAX) of the row count + one all_gather of the padded tensor."""
+    One all_gather of the row counts (read on the host: the result's shape depends on them) + one all_gather of the
+    padded tensor."""
     rank, ws = world()
     if ws == 1:
         return t
@@ -55,11 +56,44 @@ def all_gather_rows(t):
     return torch.cat([out[r * m: r * m + c] for r, c in enumerate(counts)], 0)
 
 
-def all_gather_detections(det, count, image_id):
-    """det [B, max_det, 6] fp32, count [B] int32, image_id [B] int64 (global image indices) of this
-    rank's shard -> the same three tensors for the whole set, sorted by image id."""
-    det_all = all_gather_rows(det)
-    cnt_all = all_gather_rows(count)
-    ids_all = all_gather_rows(image_id)
-    order = torch.argsort(ids_all)
-    return det_all[order], cnt_all[order], ids_all[order]
+def all_gather_detections(det, count, image_id, total=None):
+    """det [B, max_det, 6] fp32, count [B] int32, image_id [B] int64 (global image indices) of this rank's shard ->
+    the same three tensors for the whole set, sorted by image id.
+
+    ONE collective: every rank packs its rows as [detections | count | image id] (the integers ride as raw bits in
+    fp32 lanes), pads them to the largest shard and calls all_gather_into_tensor once.  With `total` (the number of
+    images of the whole set, sharded contiguously by shard_range) the pad length and every rank's row count follow
+    from arithmetic: no size exchange and no host synchronisation.  Without it the largest shard is found by one
+    all-reduce(MAX) and the rows are picked by their (non-negative) image id."""
+    rank, ws = world()
+    if ws == 1:
+        order = torch.argsort(image_id)
+        return det[order], count[order], image_id[order]
+    B, max_det = det.shape[0], det.shape[1]
+    if total is not None:
+        sizes = [shard_range(total, r, ws)[1] - shard_range(total, r, ws)[0] for r in range(ws)]
+        assert sizes[rank] == B, f"rank {rank} holds {B} images, its contiguous shard has {sizes[rank]}"
+        m = max(sizes)
+    else:
+        mt = torch.tensor([B], device=det.device, dtype=torch.int64)
+        dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+        m = int(mt.item())
+        sizes = None
+    width = max_det * 6 + 2
+    packed = det.new_zeros((m, width), dtype=torch.float32)
+    packed[:B, : max_det * 6] = det.reshape(B, max_det * 6).float()
+    ints = torch.full((m, 2), -1, device=det.device, dtype=torch.int32)      # pad rows: image id -1
+    ints[:B, 0] = count.to(torch.int32)
+    ints[:B, 1] = image_id.to(torch.int32)
+    packed[:, max_det * 6:] = ints.view(torch.float32)
+    out = packed.new_empty((ws * m, width))
+    dist.all_gather_into_tensor(out, packed.contiguous())
+    if sizes is not None:      # contiguous shards in rank order are already in image order
+        out = torch.cat([out[r * m: r * m + c] for r, c in enumerate(sizes)], 0)
+    iv = out[:, max_det * 6:].contiguous().view(torch.int32)
+    if sizes is None:
+        keep = iv[:, 1] >= 0
+        out, iv = out[keep], iv[keep]
+        order = torch.argsort(iv[:, 1].long())
+        out, iv = out[order], iv[order]
+    return out[:, : max_det * 6].reshape(-1, max_det, 6), iv[:, 0].contiguous(), iv[:, 1].long()

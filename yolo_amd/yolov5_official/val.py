@@ -3,9 +3,10 @@
 
 Differences in mechanism, not in results: forward, decode, NMS and the IoU matrices run on the GPU
 through libydet.so; detections stay in padded device tensors (`[bs, max_det, 6]` + counts) until they
-are needed on the host; when torch.distributed is initialised each rank evaluates the batches it
-owns (batch_index % world_size == rank) and the ranks exchange the padded detections and labels
-with one all-gather before the AP computation.
+are needed on the host; when torch.distributed is initialised each rank evaluates one contiguous range of
+the images (distributed.shard_range; a dataloader over an indexable dataset is re-built over just that
+range, so a rank never loads an image it does not own) and the ranks exchange the padded detections
+with one all_gather_into_tensor, the (variable-length) labels with a second, before the AP computation.
 """
 from pathlib import Path
 
@@ -24,6 +25,33 @@ def save_one_txt(predn, save_conf, shape, file):
             xywh = (xyxy2xywh(torch.tensor(xyxy).view(1, 4)) / gn).view(-1).tolist()
             line = (cls, *xywh, conf) if save_conf else (cls, *xywh)
             fh.write(("%g " * len(line)).rstrip() % line + "\n")
+
+
+def _shard_batches(dataloader, rank, world):
+    """(iterable of batches, global index of its first image, images in the whole set or None, [lo, hi) owned here).
+
+    One process: the dataloader as it is.  Several: the images are split into contiguous ranges whose boundaries fall
+    between batches (distributed.shard_range over the batches).  A torch DataLoader over an indexable dataset is
+    re-built over just this rank's range; any other iterable of batches (a list, a generator) is walked and the
+    batches outside the range are skipped without being moved to the device."""
+    if world == 1:
+        return dataloader, 0, None, (0, float("inf"))
+    ds, bs = getattr(dataloader, "dataset", None), getattr(dataloader, "batch_size", None)
+    if ds is not None and bs and hasattr(ds, "__len__") and hasattr(ds, "__getitem__"):
+        n = len(ds)
+        nbatch = (n + bs - 1) // bs
+        b0, b1 = ydist.shard_range(nbatch, rank, world)
+        lo, hi = b0 * bs, min(b1 * bs, n)
+        sub = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=bs, shuffle=False,
+                                          num_workers=getattr(dataloader, "num_workers", 0),
+                                          collate_fn=getattr(dataloader, "collate_fn", None),
+                                          pin_memory=getattr(dataloader, "pin_memory", False))
+        return sub, lo, None, (lo, hi)      # (shards of whole batches differ in size by up to a batch: sizes are exchanged)
+    batches = list(dataloader) if not isinstance(dataloader, (list, tuple)) else dataloader
+    sizes = [b[0].shape[0] for b in batches]
+    b0, b1 = ydist.shard_range(len(batches), rank, world)
+    lo, hi = sum(sizes[:b0]), sum(sizes[:b1])
+    return batches, 0, None, (lo, hi)
 
 
 @torch.no_grad()
@@ -61,10 +89,12 @@ def run(data,
 
     dets, counts, ids, tgts = [], [], [], []   # this rank's padded detections / labels in native image space
     seen_local = 0
-    img_base = 0
-    for batch_i, (img, targets, paths, shapes) in enumerate(dataloader):
+    batches, img_base, total, (lo, hi) = _shard_batches(dataloader, rank, world)
+    for batch_i, (img, targets, paths, shapes) in enumerate(batches):
         nb = img.shape[0]
-        mine = batch_i % world == rank
+        mine = lo <= img_base and img_base + nb <= hi
+        if not mine and world > 1 and img_base < hi and img_base + nb > lo:
+            raise RuntimeError("a batch straddles two ranks' image ranges: shard boundaries must fall between batches")
         if mine:
             img = img.to(dev, non_blocking=True)
             if not (img.dtype == torch.uint8 and img.is_cuda and not augment):
@@ -115,7 +145,7 @@ def run(data,
     iid = _cat(ids, (0,), torch.int64)
     tgt = _cat(tgts, (0, 6), torch.float32).float()
     # the one exchange step: padded detections + labels of every shard
-    det, cnt, iid = ydist.all_gather_detections(det, cnt, iid)
+    det, cnt, iid = ydist.all_gather_detections(det, cnt, iid, total=total)
     tgt = ydist.all_gather_rows(tgt)
 
     stats = []
