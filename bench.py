@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the other configurations (YOLOv3-tiny 416 bs1 with its CPU leg, YOLOv2-D19 416 bs32, YOLOv3-SPP "
+                         "608 bs64, YOLOv4 608 bs64), which are timed after the headline region on rank 0 of a 1-GPU run")
     ap.add_argument("--per-op", default=None, help="write a per-op timing table (tsv) to this path")
     ap.add_argument("--split", type=int, default=1, choices=[1, 2, 4],
                     help="run the forward pass as this many side-by-side launch lists over slices of the batch; with a "
@@ -227,6 +230,20 @@ def main():
             traffic = tj["kernels"][dom_label]["hbm_bytes_per_launch"]
             traffic_src = tj.get("source")
 
+    # what the NMS kernels actually move when the decode hands them its row maxima: the maxima, the rows that own a
+    # candidate above the threshold bin (85 floats each, at most max_nms of them and their neighbours in the bin), the
+    # candidate lists and the padded output
+    nms_moved = args.batch * (n_boxes * 4 + 2 * 4096 * 8 + 300 * 85 * 4 + 300 * (16 + 8) + 300 * 6 * 4)
+    # MFMA busy cycles of the dominant kernel from the committed counter passes (tools/profile_mfma.sh), if present
+    mfma_busy, mfma_src = None, None
+    mpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_mfma.json")
+    if os.path.exists(mpath):
+        with open(mpath) as fh:
+            mj = json.load(fh)
+        if dom_label in mj.get("kernels", {}):
+            mfma_busy = mj["kernels"][dom_label].get("mfma_busy_frac")
+            mfma_src = mj.get("source")
+
     result = {
         "metric": "images/sec (fwd+decode+NMS) YOLOv5s 640 bs64",
         "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -247,6 +264,7 @@ def main():
                    "weights": "seeded synthetic (yolo_amd.synthetic.init_deterministic)"},
         "roofline": {"bound": "mfma", "kernel": dom_label, "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(dom_tf / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "mfma_busy_frac_counters": mfma_busy, "mfma_counter_source": mfma_src,
                      "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                      "launches_per_step": dom["launches"] // n_ev,
                      "launches_measured": dom["launches"], "event_steps": n_ev,
@@ -258,12 +276,19 @@ def main():
                        "gflop_per_image": round(conv_flops / n_ev / args.batch / 1e9, 3)},
         "decode": "in the epilogue of the three prediction convolutions (kernel conv_head_decode)",
         "nms": {"ms_per_step": round(nms_ms, 3), "gbs": round(nms_bytes / (nms_ms * 1e-3) / 1e9, 1),
-                "frac_of_hbm_peak": round(nms_bytes / (nms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "frac_of_hbm_peak": round(nms_bytes / (nms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes": nms_bytes, "traffic_bytes": nms_moved,
+                "note": "gbs prices the unfused operator (every prediction row read once); with the decode's row maxima "
+                        "the kernels touch traffic_bytes and the time is latency (select, rank, greedy), not bandwidth"},
         "kernels": kernels,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(model, args)
+    if rank == 0 and world == 1 and not args.no_configs:
+        del model, x
+        torch.cuda.empty_cache()
+        result["configs"] = other_configs(dev, args)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -305,6 +330,86 @@ def cpu_baseline(model, args):
     return {"value": round(n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{n} images of {args.size}x{args.size} in batches of {bs}, fp32, same weights, "
                       f"forward+decode+NMS (conf 0.001, iou 0.6, multi_label), {dt:.1f} s"}
+
+
+FA_MODELS = {   # tag: (module, class, config attribute of models/model_config.py)
+    "v3tiny": ("yolo_amd.models.v3tiny", "YOLOv3", "yolov3_tiny_cfg"),
+    "v2d19": ("yolo_amd.models.v2d19", "YOLOv2", "yolov2_d19_cfg"),
+    "v3spp": ("yolo_amd.models.v3spp", "YOLOv3", "yolov3_d53_cfg"),
+    "v4": ("yolo_amd.models.v4", "YOLOv4", "yolov4_cfg"),
+}
+
+
+def build_family_a(tag, size):
+    import importlib
+    from yolo_amd.models import model_config as mc
+    from yolo_amd.synthetic import init_deterministic, scale_fa_heads
+    modname, cls, cfg = FA_MODELS[tag]
+    net = getattr(importlib.import_module(modname), cls)(size, 20, False, anchor_size=getattr(mc, cfg)["anchor_size_voc"])
+    init_deterministic(net, seed=0)
+    scale_fa_heads(net, tag)
+    return net.eval()
+
+
+def other_configs(dev, args):
+    """The other benchmark configurations, each forward + decode + per-class NMS of every image on one GPU:
+    C1 YOLOv3-tiny 416 batch 1 (with the CPU restatement of the same path on the host cores, all threads and one thread),
+    C2 YOLOv2-D19 416 batch 32, C3 YOLOv3-SPP 608 batch 64, C4 YOLOv4 608 batch 64 (its single-GPU shard)."""
+    from yolo_amd.synthetic import images
+    out = {}
+    for name, tag, size, batch, steps in (("C1", "v3tiny", 416, 1, 50), ("C2", "v2d19", 416, 32, 10), ("C3", "v3spp", 608, 64, 5),
+                                          ("C4", "v4", 608, 64, 5)):
+        net = build_family_a(tag, size).to(dev)
+        x = images(batch, size, seed=1, kind="randn").to(dev)
+        with torch.no_grad():
+            for _ in range(2):
+                net.detect_batch(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                net.detect_batch(x)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        out[name] = {"workload": f"{tag} {size}x{size} batch {batch}, forward + decode + per-class NMS", "images_per_s": round(batch / dt, 1),
+                     "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": args.compute}
+        if name == "C1" and not args.no_cpu:
+            out[name]["cpu_baseline"] = cpu_baseline_c1(net, x.cpu())
+        del net, x
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline_c1(net, x):
+    """BASELINE configuration C1 on the host: the oracle's YOLOv3-tiny (stock torch CPU ops) + numpy decode + postprocess
+    (utils/utils.py:101-133) of the one image, timed with every core torch uses and with a single thread."""
+    from oracle import nets as ON
+    from oracle import postproc as OP
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    anchors = [np.asarray(a, np.float32).reshape(-1, 2) for a in net._level_anchors()]
+
+    def one():
+        with torch.no_grad():
+            heads = ON.v3tiny_heads(sd, x)
+        bb, sc = OP.fa_decode([h.numpy() for h in heads], anchors, net.num_anchors, net.num_classes, net.decode_v2, net.input_size)
+        with np.errstate(all="ignore"):
+            OP.postprocess(bb[0], sc[0], net.conf_thresh, net.num_classes, net.nms_thresh)
+
+    res = {}
+    all_threads = torch.get_num_threads()
+    for label, nthreads in (("all_threads", all_threads), ("one_thread", 1)):
+        torch.set_num_threads(nthreads)
+        one()
+        t0 = time.perf_counter()
+        n = 0
+        while n < 10 or time.perf_counter() - t0 < 4.0:
+            one()
+            n += 1
+        dt = time.perf_counter() - t0
+        res[label] = {"value": round(n / dt, 3), "unit": "images/s", "cores": nthreads, "iterations": n}
+    torch.set_num_threads(all_threads)
+    res["kind"] = "port"
+    res["sample"] = "one 416x416 image per iteration, fp32, same weights, forward + decode + postprocess (conf 0.001, nms 0.5)"
+    return res
 
 
 if __name__ == "__main__":
