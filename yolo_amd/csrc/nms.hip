@@ -611,12 +611,34 @@ struct FAArgs {
     unsigned* cursor;     // [N][nc]
     unsigned* seg;        // [N][n]  box indices grouped by class
     unsigned* sorted;     // [N][n]  same, sorted by descending score inside each class
+    float4* sbox;         // [N][n]  the boxes in that order (one gather, then contiguous reads)
+    unsigned* alive;      // [N][n]  second index list of the greedy kernel (the first one reuses seg)
 };
 
 // argmax class (first maximum), threshold, per-class population count.  The 256 boxes of a workgroup are one
 // contiguous run of the score matrix: it is staged through LDS in coalesced order (a thread reading its own nc values
 // straight from memory touches a different cache line than each of its neighbours).
 constexpr int kFaScoreMaxNc = 40;     // 256 * nc floats of LDS; wider score rows take the direct path
+
+// atomicAdd(&counter[key], 1) for the lanes with `on`, one atomic per distinct key of the wave instead of one per
+// lane (thousands of boxes of an image share a handful of argmax classes: per-lane atomics on those few words run
+// one after the other).  Returns the value the lane's own add would have returned, in lane order within the wave.
+__device__ __forceinline__ unsigned wave_count_add(unsigned* counter, bool on, unsigned key) {
+    const int lane = threadIdx.x & 63;
+    unsigned result = 0;
+    u64 todo = __ballot(on);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
+        const u64 same = __ballot(on && key == k0);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&counter[k0], (unsigned)__popcll(same));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+        if (on && key == k0) result = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return result;
+}
 
 __global__ __launch_bounds__(256) void fa_score_kernel(const FAArgs a) {
     __shared__ float tile[256 * kFaScoreMaxNc];
@@ -642,7 +664,7 @@ __global__ __launch_bounds__(256) void fa_score_kernel(const FAArgs a) {
     a.cls[gid] = bj;
     a.best[gid] = best;
     a.keep[gid] = 0;
-    if (best >= a.conf) atomicAdd(&a.count[(size_t)img * a.nc + bj], 1u);
+    wave_count_add(a.count, best >= a.conf, (unsigned)img * (unsigned)a.nc + (unsigned)bj);
 }
 
 __device__ __forceinline__ unsigned fa_class_offset(const unsigned* count, int cls) {
@@ -653,14 +675,14 @@ __device__ __forceinline__ unsigned fa_class_offset(const unsigned* count, int c
 
 __global__ __launch_bounds__(256) void fa_scatter_kernel(const FAArgs a) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)a.N * a.n) return;
-    if (!(a.best[gid] >= a.conf)) return;
-    const int img = (int)(gid / a.n);
+    const bool in = gid < (long long)a.N * a.n;
+    const bool on = in && a.best[in ? gid : 0] >= a.conf;
+    const int img = in ? (int)(gid / a.n) : 0;
+    const int c = on ? a.cls[gid] : 0;
+    const unsigned slot = wave_count_add(a.cursor, on, (unsigned)img * (unsigned)a.nc + (unsigned)c);   // (every lane takes part)
+    if (!on) return;
     const unsigned box = (unsigned)(gid - (long long)img * a.n);
-    const int c = a.cls[gid];
-    const unsigned pos = fa_class_offset(a.count + (size_t)img * a.nc, c) +
-                         atomicAdd(&a.cursor[(size_t)img * a.nc + c], 1u);
-    a.seg[(size_t)img * a.n + pos] = box;
+    a.seg[(size_t)img * a.n + fa_class_offset(a.count + (size_t)img * a.nc, c) + slot] = box;
 }
 
 // grid (chunk, class, image): rank of each member inside its class segment.
@@ -693,27 +715,123 @@ __global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
         const unsigned lim = min(256u, cnt - t0);
         for (unsigned q = 0; q < lim; ++q) rank += tk[q] > mykey ? 1u : 0u;
     }
-    if (m < cnt) a.sorted[(size_t)img * a.n + off + rank] = mybox;
+    if (m < cnt) {
+        a.sorted[(size_t)img * a.n + off + rank] = mybox;
+        a.sbox[(size_t)img * a.n + off + rank] = reinterpret_cast<const float4*>(a.boxes)[(size_t)img * a.n + mybox];
+    }
 }
 
 constexpr int kFaMaxWords = 2048;  // up to 131072 boxes per class segment
 
 constexpr int kFaNmsThreads = 1024;   // four threads per later box when a chunk's survivors are applied (long class segments)
 
+// One workgroup per (class, image) segment, boxes in descending score order.  The greedy rule of utils/utils.py:15-42
+// in rounds: the first 64 boxes still alive form a chunk, its 64 x 64 "i suppresses j" matrix is built in parallel
+// and resolved serially by one wave (readlane'd row masks), then every other box still alive is tested against the
+// chunk's kept boxes and the survivors are written, in order, to the second index list.  A segment of thousands of
+// boxes of which a few hundred survive shrinks geometrically: the work is the sum of the alive counts, not
+// (segment length) x (chunks).
 __global__ __launch_bounds__(kFaNmsThreads) void fa_nms_kernel(const FAArgs a) {
     __shared__ NmsShared sh;
-    __shared__ u64 removed[kFaMaxWords], kept[kFaMaxWords];
-    const int img = blockIdx.y, c = blockIdx.x;
+    __shared__ unsigned s_entry[64];
+    __shared__ unsigned s_wcnt[kFaNmsThreads / 64];
+    __shared__ unsigned s_out;
+    const int img = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned* count = a.count + (size_t)img * a.nc;
     const int cnt = (int)count[c];
     if (cnt == 0) return;
     const unsigned off = fa_class_offset(count, c);
     const unsigned* sorted = a.sorted + (size_t)img * a.n + off;
-    const float4* boxes = reinterpret_cast<const float4*>(a.boxes) + (size_t)img * a.n;
-    greedy_nms_block<true, kFaNmsThreads>(cnt, a.thr, [&](int s) { return boxes[sorted[s]]; }, sh, removed, kept);
+    const float4* sbox = a.sbox + (size_t)img * a.n + off;
+    unsigned* cur = a.seg + (size_t)img * a.n + off;      // (the class lists are no longer needed once ranked)
+    unsigned* nxt = a.alive + (size_t)img * a.n + off;
     uint8_t* keep = a.keep + (size_t)img * a.n;
-    for (int s = threadIdx.x; s < cnt; s += kFaNmsThreads)
-        if ((kept[s >> 6] >> (s & 63)) & 1ull) keep[sorted[s]] = 1;
+    for (int s = tid; s < cnt; s += kFaNmsThreads) cur[s] = (unsigned)s;
+    __syncthreads();
+    int L = cnt;
+    while (L > 0) {
+        const int cn = min(64, L);
+        if (tid < 64) {
+            const unsigned e = tid < cn ? cur[tid] : 0u;
+            const float4 b = tid < cn ? sbox[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s_entry[tid] = e;
+            sh.cbox[tid] = b;
+            sh.carea[tid] = box_area(b);
+        }
+        if (tid == 0) s_out = 0;
+        __syncthreads();
+        {   // the chunk's matrix: thread (i = tid / 16, part = tid % 16) tests j = 4 part .. 4 part + 3, j > i
+            constexpr int PARTS = kFaNmsThreads / 64, PER = 64 / PARTS;
+            const int i = tid / PARTS, part = tid % PARTS;
+            u64 bits = 0;
+            if (i < cn) {
+                const float4 bi = sh.cbox[i];
+                const float ai = sh.carea[i];
+#pragma unroll
+                for (int jj = 0; jj < PER; ++jj) {
+                    const int j = part * PER + jj;
+                    if (j > i && j < cn && suppresses<true>(bi, ai, sh.cbox[j], sh.carea[j], a.thr)) bits |= 1ull << j;
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < PARTS; d <<= 1) bits |= __shfl_xor(bits, d);
+            if (part == 0) sh.rowmask[i] = bits;
+        }
+        __syncthreads();
+        if (tid < 64) {          // serial resolve: every box of the chunk was alive when the round began
+            const u64 mine = tid < cn ? sh.rowmask[tid] : 0ull;
+            const u64 valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+            u64 rem = 0, kp = 0, cand = valid;
+            while (cand) {
+                const int i = __ffsll((long long)cand) - 1;
+                kp |= 1ull << i;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, i);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), i);
+                rem |= ((u64)hi << 32) | (u64)lo;
+                cand = ~rem & valid & ~(((1ull << i) << 1) - 1ull);
+            }
+            if ((kp >> tid) & 1ull) keep[sorted[s_entry[tid]]] = 1;
+            if (tid == 0) sh.kept_word = kp;
+        }
+        __syncthreads();
+        const u64 kp = sh.kept_word;
+        // every other box still alive against the chunk's kept boxes; survivors to the other list, order preserved
+        for (int t0 = 64; t0 < L; t0 += kFaNmsThreads) {
+            const int pos = t0 + tid;
+            bool survives = false;
+            unsigned e = 0;
+            if (pos < L) {
+                e = cur[pos];
+                const float4 bj = sbox[e];
+                const float aj = box_area(bj);
+                survives = true;
+                u64 m = kp;
+                while (m) {
+                    const int i = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (suppresses<true>(sh.cbox[i], sh.carea[i], bj, aj, a.thr)) { survives = false; break; }
+                }
+            }
+            const u64 bal = __ballot(survives);
+            if (lane == 0) s_wcnt[wv] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kFaNmsThreads / 64; ++w) {
+                const unsigned cw = s_wcnt[w];
+                if (w < wv) before += cw;
+                total += cw;
+            }
+            const unsigned base = s_out;
+            if (survives) nxt[base + before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = e;
+            __syncthreads();
+            if (tid == 0) s_out = base + total;
+        }
+        __syncthreads();
+        L = (int)s_out;
+        unsigned* t = cur; cur = nxt; nxt = t;
+        __syncthreads();
+    }
 }
 
 size_t fa_ws_layout(int N, int n, int nc, size_t* o_count, size_t* o_cursor, size_t* o_seg, size_t* o_sorted) {
@@ -723,6 +841,8 @@ size_t fa_ws_layout(int N, int n, int nc, size_t* o_count, size_t* o_cursor, siz
     const size_t c1 = take((size_t)N * nc * sizeof(unsigned));
     const size_t sg = take((size_t)N * n * sizeof(unsigned));
     const size_t so = take((size_t)N * n * sizeof(unsigned));
+    take((size_t)N * n * sizeof(float4));      // sorted boxes: right behind `sorted`
+    take((size_t)N * n * sizeof(unsigned));    // second index list
     if (o_count) { *o_count = c0; *o_cursor = c1; *o_seg = sg; *o_sorted = so; }
     return off;
 }
@@ -1049,6 +1169,11 @@ extern "C" int ydet_nms_perclass(const float* boxes, const float* scores, int N,
     a.keep = out_keep; a.cls = out_cls; a.best = out_score;
     a.count = (unsigned*)(ws + oc); a.cursor = (unsigned*)(ws + ou);
     a.seg = (unsigned*)(ws + og); a.sorted = (unsigned*)(ws + os);
+    {
+        const size_t idx = ((size_t)N * n * sizeof(unsigned) + 255) & ~(size_t)255, bx = ((size_t)N * n * sizeof(float4) + 255) & ~(size_t)255;
+        a.sbox = (float4*)(ws + os + idx);
+        a.alive = (unsigned*)(ws + os + idx + bx);
+    }
     if (hipMemsetAsync(ws + oc, 0, og - oc, s) != hipSuccess)
         return fail(YDET_ERR_LAUNCH, "nms_perclass: hipMemsetAsync failed");
     const long long total = (long long)N * n;
