@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeat", type=int, default=0, help="diagnostic: time the K steps this many more times (reported as repeat_ms)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
@@ -50,10 +51,13 @@ def main():
     ap.add_argument("--split", type=int, default=1, choices=[1, 2, 4],
                     help="run the forward pass as this many side-by-side launch lists over slices of the batch; with a "
                          "split the per-kernel events are taken in a second, unsplit loop outside the timed region")
-    ap.add_argument("--event-every", type=int, default=10,
+    ap.add_argument("--event-every", type=int, default=0,
                     help="per-op events (kernel durations for the roofline object) are recorded on every E-th timed "
-                         "step: an event costs 2-3 us of stream time, 55 of them per step are 5 %% of it, and "
-                         "such a step runs alone on the GPU (it drains the pipeline of batches)")
+                         "step; 0 (default): on the last step of the timed region.  A step with events runs alone on "
+                         "the GPU (so that a kernel's interval holds that kernel only), which drains the pipeline of "
+                         "batches on the other streams, and its enqueue is host-bound (an event record per kernel): "
+                         "as the last step it is enqueued while the GPU still works through the steps before it and "
+                         "the pipeline is about to drain anyway; anywhere else it costs one to two steps")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches are issued round-robin on this many HIP streams (each with its own plan / activation "
                          "arena), so the tail of one batch's kernels and its small-grid NMS overlap the next batch; the "
@@ -141,7 +145,10 @@ def main():
         lib.ydet_timer_destroy(cal_t)
         event_ms = max(diffs[ncal // 2] / (n_ops + 3), 0.0)      # median over the pairs
         event_src = "a step alone with its events minus the same step without, per event (median of 9 pairs before the timed region)"
-        sampled = [k for k in range(args.steps) if k % max(args.event_every, 1) == 0]   # steps that carry events
+        if args.event_every > 0:
+            sampled = [k for k in range(args.steps) if k % args.event_every == 0]   # steps that carry events
+        else:
+            sampled = [args.steps - 1]
         n_ev = len(sampled)
         timer = lib.ydet_timer_create(n_ev * (n_ops + 1))
         if not timer:
@@ -165,6 +172,14 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
+        repeat_ms = []
+        for _ in range(args.repeat):      # diagnostic: the same K steps again (no events), to see the run-to-run spread
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            for k in range(args.steps):
+                step(k % S)
+            torch.cuda.synchronize()
+            repeat_ms.append(round((time.perf_counter() - r0) / args.steps * 1e3, 3))
         if split:   # kernel statistics: the same steps again as ONE launch list, events after every op
             engine.set_batch_split(1)
             model.invalidate_plans()
@@ -252,6 +267,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        **({"repeat_ms": repeat_ms} if repeat_ms else {}),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=25)
     ap.add_argument("--burst", type=int, default=8)
     ap.add_argument("--shapes", default="", help="extra shapes N,H,W,Cin,Cout,k,s,res;...")
+    ap.add_argument("--tiles", nargs="*", default=[], help="YDET_CONV_TILE per library ('-' for none): each library reads "
+                    "the variable once, at its first launch, so copies of one build can run different forced tiles")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -94,6 +96,15 @@ def main():
             d.res_mode = _ffi.RES_AFTER_ACT if res else _ffi.RES_NONE
             d.in_dtype = d.out_dtype = _ffi.BF16
             ds.append(d)
+        for li, (name, h) in enumerate(libs):      # first launch of every library under its own environment
+            tile = args.tiles[li] if li < len(args.tiles) else "-"
+            if tile != "-":
+                os.environ["YDET_CONV_TILE"] = tile
+            else:
+                os.environ.pop("YDET_CONV_TILE", None)
+            if h.ydet_conv2d_nhwc(ds[li], stream) != 0:
+                raise RuntimeError(f"{name}: {h.ydet_last_error().decode()}")
+        torch.cuda.synchronize()
         times = [[] for _ in libs]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for rnd in range(args.rounds + 3):

@@ -243,22 +243,29 @@ constexpr int conv_dma_min_waves(int bn, int bm, int nw, bool head) {
     return head ? 1 : nw == 8 ? 4 : (nw == 4 && bn == 128 && bm == 128) ? 3 : 1;
 }
 
-template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool HEAD = false>
+// KCH: 16-byte chunks per LDS row = K extent of a ring stage (4: 64-byte rows, 32 bf16 of K per step; 8: 128-byte rows,
+// two MFMA K-substeps per step, every LDS-DMA instruction fetches whole 128-byte lines).  NST: stages of the ring.
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool HEAD = false, int KCH = 4, int NST = 3>
 __global__ __launch_bounds__(64 * WARPS_N * WARPS_M, conv_dma_min_waves(BN, BM, WARPS_N * WARPS_M, HEAD))
 void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     constexpr int NW = WARPS_N * WARPS_M;         // waves per workgroup (4 or 8)
     constexpr int NT = 64 * NW;
     static_assert(NW == 4 || NW == 8 || NW == 16, "four, eight or sixteen waves per workgroup");
     constexpr int EPC = 16 / (int)sizeof(TIN);
-    constexpr int BK = 4 * EPC;
+    static_assert(KCH == 4 || (KCH == 8 && sizeof(TIN) == 2 && !HEAD), "128-byte rows: bf16 inputs, no decoding head");
+    static_assert(NST >= 2 && NST <= 4, "two to four ring stages");
+    constexpr int BK = KCH * EPC;
+    constexpr int RB = KCH * 16;                  // bytes per LDS row
+    constexpr int RPI = 64 / KCH;                 // rows one LDS-DMA instruction (64 lanes x 16 bytes) fills
+    constexpr int KSUB = KCH / 4;                 // MFMA K-substeps per ring stage
     constexpr int WN = BN / WARPS_N, WM = BM / WARPS_M;
     constexpr int FN = WN / 16, FM = WM / 16;
-    constexpr int WROWS = BN < 16 * NW ? 16 * NW : BN;   // weight rows staged (so every wave stages whole 16-row groups)
-    constexpr int WJ = WROWS / (16 * NW), XJ = BM / (16 * NW);  // 16-row groups per wave: weights, pixels
-    static_assert(WJ >= 1 && XJ >= 1 && WROWS % (16 * NW) == 0 && BM % (16 * NW) == 0, "tile too small for the wave count");
+    constexpr int WROWS = BN < RPI * NW ? RPI * NW : BN;   // weight rows staged (so every wave stages whole row groups)
+    constexpr int WJ = WROWS / (RPI * NW), XJ = BM / (RPI * NW);  // row groups per wave: weights, pixels
+    static_assert(WJ >= 1 && XJ >= 1 && WROWS % (RPI * NW) == 0 && BM % (RPI * NW) == 0, "tile too small for the wave count");
     constexpr int LPT = WJ + XJ;                  // LDS-DMA instructions per wave and tile
-    constexpr int STAGE = (WROWS + BM) * 64;
-    constexpr int NSTAGE = 3;
+    constexpr int STAGE = (WROWS + BM) * RB;
+    constexpr int NSTAGE = NST;
     using frag_t = typename Frag<TIN>::type;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -291,11 +298,14 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     }
 
     // ---- staging roles ------------------------------------------------------------------------------
-    // wave-instruction j of a wave fills LDS rows (j*NW + wave)*16 .. +15 of the weight (j < WJ) or pixel
-    // image; lane l lands at physical chunk l&3 of row l>>2 and therefore fetches logical chunk
-    // (l&3) ^ F[(l>>4)&3] (the swizzle lives on the source address, the LDS image stays lane-linear).
-    const int srow = lane >> 2;
-    const int lchunk = (lane & 3) ^ chunk_swz(lane >> 4);
+    // wave-instruction j of a wave fills LDS rows (j*NW + wave)*RPI .. +RPI-1 of the weight (j < WJ) or pixel
+    // image; lane l lands at physical chunk l % KCH of row l / KCH and therefore fetches logical chunk
+    // (l % KCH) ^ swizzle(row & 15) (the swizzle lives on the source address, the LDS image stays lane-linear).
+    // 64-byte rows: swizzle F[(row >> 2) & 3]; 128-byte rows: (row >> 1) & 7 -- either way the sixteen rows a
+    // ds_read_b128 lane group reads at one logical chunk fall on sixteen different 16-byte bank groups.
+    auto row_swz = [](int row15) { return KCH == 4 ? chunk_swz(row15 >> 2) : (row15 >> 1) & 7; };
+    const int srow = lane / KCH;
+    const int lchunk = (lane % KCH) ^ row_swz((wave * RPI + srow) & 15);
     // Which output channel sits on which row of the weight image is free.  With bf16 outputs row (i, r) of a wave's WN
     // rows (fragment i, MFMA row r = 4 q + e) takes channel 32 (i>>1) + 8 q + 4 (i&1) + e: the accumulator rows a lane
     // ends up with in fragments 2 s and 2 s + 1 are then EIGHT CONSECUTIVE channels (one 16-byte piece), and the four
@@ -305,7 +315,7 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     const char* wsrc[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-        const int R = (j * NW + wave) * 16 + srow;
+        const int R = (j * NW + wave) * RPI + srow;
         int ch = R;
         if (PERM && R < BN) {
             const int i = (R % WN) >> 4, r = R & 15;
@@ -335,7 +345,7 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-        const int row = (j * NW + wave) * 16 + srow;
+        const int row = (j * NW + wave) * RPI + srow;
         const long long m = m0 + row;
         const bool okm = m < a.M;
         if (pointwise) {
@@ -403,7 +413,7 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
             const bool ok = (xmask[j] >> tap) & 1u;
             const char* src = ok ? (from_up ? xup[j] : xsrc[j]) + tapoff : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + WROWS * 64 + j * (NW * 1024)), 16,
+                                             (__attribute__((address_space(3))) void*)(dst + WROWS * RB + j * (NW * 1024)), 16,
                                              0, 0);
         }
         ++ktile;
@@ -422,7 +432,9 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int fr_off = (lane & 15) * 64 + (((lane >> 4) ^ chunk_swz(lane >> 2)) << 4);
+    int fr_off[KSUB];
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk) fr_off[kk] = (lane & 15) * RB + (((4 * kk + (lane >> 4)) ^ row_swz(lane & 15)) << 4);
 
     // weights of a 1x1 follower (see below): requested now, so that their latency runs under the K loop
     constexpr bool PW_OK = WARPS_N == 1 && BN == 64 && !HEAD && sizeof(TIN) == 2;
@@ -444,40 +456,49 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
 
     const int nk = a.kp / BK;
     YDET_STAMP(1);
-    issue(0);
-    if (nk > 1) issue(1);
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p)
+        if (p < nk) issue(p);
     YDET_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most one younger tile (LPT instructions) is still in flight
-        if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        // tile kt has landed once at most the younger tiles issued so far (NSTAGE - 2 of them, fewer at the end;
+        // LPT instructions each) are still in flight
+        if (NSTAGE >= 4 && kt + 2 < nk) wait_vmcnt<2 * LPT>();
+        else if (NSTAGE >= 3 && kt + 1 < nk) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         YDET_STAMP(3 + kt);
         // this step's operand fragments are requested first, so that their LDS latency runs under the address
         // arithmetic and issue of the refill below instead of in front of the MFMAs
-        const char* ws = smem + (kt % NSTAGE) * STAGE + (wn * WN) * 64 + fr_off;
-        const char* xs = smem + (kt % NSTAGE) * STAGE + WROWS * 64 + (wm * WM) * 64 + fr_off;
-        frag_t fa[FN], fb[FM];
+        const char* ws = smem + (kt % NSTAGE) * STAGE + (wn * WN) * RB;
+        const char* xs = smem + (kt % NSTAGE) * STAGE + WROWS * RB + (wm * WM) * RB;
+        frag_t fa[KSUB][FN], fb[KSUB][FM];
 #ifdef YDET_EXP_NO_LDSREAD
         if (kt == 0) {
 #endif
 #pragma unroll
-        for (int i = 0; i < FN; ++i) fa[i] = *reinterpret_cast<const frag_t*>(ws + i * 16 * 64);
+        for (int kk = 0; kk < KSUB; ++kk) {
 #pragma unroll
-        for (int j = 0; j < FM; ++j) fb[j] = *reinterpret_cast<const frag_t*>(xs + j * 16 * 64);
+            for (int i = 0; i < FN; ++i) fa[kk][i] = *reinterpret_cast<const frag_t*>(ws + fr_off[kk] + i * 16 * RB);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) fb[kk][j] = *reinterpret_cast<const frag_t*>(xs + fr_off[kk] + j * 16 * RB);
+        }
 #ifdef YDET_EXP_NO_LDSREAD
         }
 #endif
         asm volatile("" ::: "memory");   // keep the reads above the refill
-        // every wave is past its reads of stage (kt-1)%3 == (kt+2)%3: refill it
-        if (kt + 2 < nk) issue((kt + 2) % NSTAGE);
+        // every wave is past its reads of stage (kt - 1) % NSTAGE: refill it with tile kt + NSTAGE - 1
+        if (kt + NSTAGE - 1 < nk) issue((kt + NSTAGE - 1) % NSTAGE);
 #ifdef YDET_EXP_NO_MFMA
         if (kt == 0)
 #endif
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+        for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = mma(fa[kk][i], fb[kk][j], acc[i][j]);
     }
 
     // ---- optional 1x1 follower on the tile in registers ------------------------------------------------------
@@ -861,20 +882,25 @@ int launch_direct(const ConvArgs& a, hipStream_t stream) {
     return YDET_OK;
 }
 
-template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M>
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, int KCH = 4, int NST = 3>
 int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const long long tiles_m = (a.M + BM - 1) / BM;
     const long long nblk = tiles_m * a.tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(YDET_ERR_ARG, "conv: grid of %lld blocks", nblk);
-    constexpr int BK = 64 / (int)sizeof(TIN);
+    constexpr int BK = KCH * 16 / (int)sizeof(TIN);
+    if constexpr (KCH != 4) {
+        if (a.Cin % BK != 0 || a.KH * a.KW > 32)
+            return fail(YDET_ERR_ARG, "conv: the %d-byte-row tile needs Cin to be a multiple of %d", KCH * 16, BK);
+    }
     // uniform-tap LDS-DMA kernel; the 32-channel tile keeps the register-staged kernel (measured faster there:
     // its weight image is half padding under the DMA group layout)
     if (BN >= 64 && a.Cin % BK == 0 && a.KH * a.KW <= 32) {
         constexpr int NW = WARPS_N * WARPS_M;
-        constexpr int WROWS = BN < 16 * NW ? 16 * NW : BN;
-        const size_t lds_dma = 3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float);
+        constexpr int RPI = 64 / KCH;
+        constexpr int WROWS = BN < RPI * NW ? RPI * NW : BN;
+        const size_t lds_dma = NST * (size_t)(WROWS + BM) * (KCH * 16) + 3 * BN * sizeof(float);
         // 16-byte pieces straight from registers: output (and residual) slices must be 16-byte aligned
         a.lds_epilogue = (a.y_ld % (16 / (int)sizeof(TOUT)) == 0 && a.y_coff % (16 / (int)sizeof(TOUT)) == 0 &&
                           a.cout_store % (16 / (int)sizeof(TOUT)) == 0 &&
@@ -883,12 +909,13 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
                              : 0;
         if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
             static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (size_t)(WROWS + BM) * 64 + 3 * BN * sizeof(float)));
+                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST>),
+                hipFuncAttributeMaxDynamicSharedMemorySize,
+                (int)(NST * (size_t)(WROWS + BM) * (KCH * 16) + 3 * BN * sizeof(float)));
             if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         }
         if (a.y2 && !a.lds_epilogue) return fail(YDET_ERR_ARG, "conv: a second destination needs 16-byte aligned output slices");
-        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false>), dim3((unsigned)nblk),
+        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST>), dim3((unsigned)nblk),
                            dim3(64 * NW), lds_dma, stream, a, HeadArgs{});
         YDET_CHECK_LAUNCH("conv_dma_kernel");
         return YDET_OK;
@@ -896,7 +923,7 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     if (a.y2) return fail(YDET_ERR_ARG, "conv: a second destination needs Cin to be a multiple of %d and at least 64 output channels", BK);
     if (a.pw_w) return fail(YDET_ERR_ARG, "conv: a 1x1 follower needs the LDS-DMA kernel");
     if (a.x_up) return fail(YDET_ERR_ARG, "conv: an upsampled source needs the LDS-DMA kernel (Cin a multiple of %d, more than 32 output channels)", BK);
-    if constexpr (WARPS_N * WARPS_M != 4) {
+    if constexpr (WARPS_N * WARPS_M != 4 || KCH != 4) {
         return fail(YDET_ERR_ARG, "conv: the %dx%d tile needs Cin to be a multiple of %d", BN, BM, BK);
     } else {
         const size_t lds = 2 * (size_t)(BN + BM) * 64;
@@ -935,8 +962,17 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
     // YDET_CONV_TILE=<channels>x<pixels> forces a tile shape (tuning aid)
     static const char* forced = getenv("YDET_CONV_TILE");
     if (forced) {
-        int bn = 0, bm = 0;
-        if (sscanf(forced, "%dx%d", &bn, &bm) == 2) {
+        int bn = 0, bm = 0, kch = 4, nst = 3;
+        const int got = sscanf(forced, "%dx%dk%ds%d", &bn, &bm, &kch, &nst);
+        if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
+            // <channels>x<pixels>k8s<stages>: the 128-byte-row variants (where Cin is a multiple of 64; other layers
+            // keep the default choice)
+            if (got == 4 && kch == 8 && a.Cin % 64 == 0 && a.KH * a.KW <= 32 && a.Cout > 64) {
+                if (bn == 128 && bm == 128 && nst == 2) return launch_tile<TIN, TOUT, 128, 128, 2, 2, 8, 2>(a, stream);
+                if (bn == 128 && bm == 64 && nst == 3) return launch_tile<TIN, TOUT, 128, 64, 2, 2, 8, 3>(a, stream);
+            }
+        }
+        if (got == 2) {
             if (bn == 32 && bm == 256) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
             if (bn == 64 && bm == 128) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
             if (bn == 128 && bm == 128) return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
@@ -953,6 +989,16 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
     }
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
     if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
+    if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
+        // Few tiles and a long K: the launch is one or two rounds of workgroups whose time is the K loop's, and the
+        // 128-byte-row variant walks K in half as many steps (half the barriers and waits; two stages of twice the
+        // size).  With many tiles per CU the three-stage ring at three workgroups per CU hides more (measured).
+        const long long tiles = (a.M + 127) / 128 * ((a.Cout + 127) / 128);
+        const int K = a.KH * a.KW * a.Cin;
+        static const bool k8_on = !(getenv("YDET_CONV_K8") && atoi(getenv("YDET_CONV_K8")) == 0);
+        if (k8_on && a.Cin % 64 == 0 && a.KH * a.KW <= 32 && K >= 256 && (tiles <= 512 || (tiles <= 1024 && K >= 2048)))
+            return launch_tile<TIN, TOUT, 128, 128, 2, 2, 8, 2>(a, stream);
+    }
     if (sizeof(TOUT) == 2 && wide_tile_pays(a.M, a.Cout, a.KH * a.KW * a.Cin, a.Cin % (64 / (int)sizeof(TIN)) == 0 && a.KH * a.KW <= 32))
         return launch_tile<TIN, TOUT, 128, 256, 2, 4>(a, stream);
     return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
