@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 12
+#define YDET_ABI_VERSION 13
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -138,6 +138,17 @@ int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
  * x_dtype YDET_U8: the image holds raw 0..255 pixel values and every value enters as bf16(float(v) / 255), the
  * `img.float() / 255` of yolov5_official/val.py:68-69 folded into the load (the fp32 image is never written). */
 int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
+
+/* Focus + the first convolution + the SECOND convolution (+ its 1x1 follower) as one kernel, straight from the NCHW
+ * image: rows 0-1 of yolov5_official/yamls/yolov5s.yaml's backbone, `Focus(3, 32, 3)` and `Conv(32, 64, 3, 2)`
+ * (yolov5_official/modules.py:285-293, :34-46), and through next->pw_w the cv1 | cv2 pair of the C3 in row 2
+ * (modules.py:242-253).  The 32-channel map between the two layers -- the largest tensor of the network -- exists only
+ * as patches in LDS.  `focus` as for ydet_focus_conv3x3_nchw with Cout = 32 (its y is not used); `next` as for
+ * ydet_conv2d_nhwc: 3x3 / stride 2 / pad 1, Cin = 32, Cout = 64, H x W the half-size map, kp = 288 (its x is not used),
+ * optionally with a follower (pw_w, pw_bias, pw_cout, pw_kp = 64) and a second destination (y2, y_split); no res, post_*,
+ * x_up or cout_store.  bf16 weights and output.  Same bf16 intermediate values and accumulation order as the layers run
+ * one by one. */
+int ydet_focus_conv_pair_nchw(const ydet_conv_desc* focus, const ydet_conv_desc* next, int x_dtype, void* stream);
 
 /* The first layer of the Darknet-style trunks straight from the NCHW image: `Conv(3, C, k=3, p=1)` (utils/moduleUtils.py:8-24
  * as used at models/basemodel/d19.py:22,88,133,175,221) including the NCHW -> NHWC edge conversion.  d->x is the image
@@ -424,7 +435,8 @@ typedef enum {
     YDET_OP_HEAD_DECODE = 10,  /* conv + head: as ydet_head_conv_decode */
     YDET_OP_BOTTLENECK = 11,/* conv + conv2: as ydet_bottleneck_fused */
     YDET_OP_C3_TAIL = 12,   /* conv + conv2 + conv3: as ydet_c3_tail_fused */
-    YDET_OP_RGB_CONV = 13   /* conv: as ydet_rgb_conv3x3_nchw; iarg3 = image dtype */
+    YDET_OP_RGB_CONV = 13,  /* conv: as ydet_rgb_conv3x3_nchw; iarg3 = image dtype */
+    YDET_OP_FOCUS_PAIR = 14 /* conv + conv2: as ydet_focus_conv_pair_nchw; iarg3 = image dtype */
 } ydet_op_kind;
 
 typedef struct {

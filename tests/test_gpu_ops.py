@@ -571,6 +571,55 @@ def test_focus_stem_fused(shape, cout, src):
     assert rel_err(outs["bf16"], ref) < 2e-2
 
 
+# ---- Focus + the stride-2 convolution behind it (+ the C3's cv1 | cv2) as one kernel -------------------------------
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 50, 70), (1, 3, 36, 132), (3, 3, 16, 16)])
+@pytest.mark.parametrize("tail", ["conv", "c3", "conv_leaky"])
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16, torch.uint8])
+def test_focus_pair_fused(shape, tail, src):
+    """Focus(3, 32, 3) -> Conv(32, 64, 3, 2) [-> C3(64, 64)]: image sizes that are not multiples of the patch of 8 x 16
+    output pixels (odd half-size maps included), with and without the 1x1 follower / second destination, fp32 / bf16 /
+    raw uint8 images.  The fused launch against the layers run one by one (same bf16 intermediate values and accumulation
+    order: equal up to single bf16 ulps where an epilogue contracts differently) and against torch fp32."""
+    from yolo_amd.yolov5_official.modules import C3, Conv, Focus
+    from yolo_amd.synthetic import init_deterministic
+    mods = [Focus(3, 32, 3), Conv(32, 64, 3, 2)] + ([C3(64, 64, 1)] if tail == "c3" else [])
+    net = nn.Sequential(*mods)
+    if tail == "conv_leaky":
+        mods[0].conv.act = mods[1].act = nn.LeakyReLU(0.1)
+    init_deterministic(net, seed=11)
+    net.eval()
+    gen = _gen(21, f"pair{shape}")
+    if src == torch.uint8:
+        x = torch.randint(0, 256, shape, generator=gen, dtype=torch.uint8)
+        xf = x.float() / 255.0
+    else:
+        x = torch.randn(*shape, generator=gen).to(src)
+        xf = x.float()
+    with torch.no_grad():
+        ref = net(xf)
+    net = net.to(DEV)
+    outs = {}
+    for fused in (True, False):
+        engine.set_focus_pair_fusion(fused)
+        try:
+            g = engine.Graph(DEV, "bf16")
+            act, slope = (_ffi.ACT_LEAKY, 0.1) if tail == "conv_leaky" else (_ffi.ACT_SILU, 0.0)
+            t = g.focus_stem(*shape, mods[0].conv.conv, mods[0].conv.bn, act=act, slope=slope)
+            for m in mods[1:]:
+                t = m.lower(g, t)
+            g.to_nchw(t, "y")
+            plan = g.finalize()
+            kinds = [k for k, _ in g.ops]
+            assert kinds[0] == ("focus_pair" if fused else "focus_conv"), kinds
+            outs[fused] = plan.run(x.to(DEV))["y"].float().cpu()
+        finally:
+            engine.set_focus_pair_fusion(True)
+    assert outs[True].shape == ref.shape
+    assert rel_err(outs[True].numpy(), outs[False].numpy()) < 1e-2
+    assert (outs[True] != outs[False]).float().mean() < 0.02
+    assert rel_err(outs[True].numpy(), ref.numpy()) < 2e-2
+
+
 # ---- 32-channel bottleneck as one kernel ---------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 32, 16, 64), (1, 32, 13, 37), (3, 32, 40, 40), (1, 32, 5, 3),
                                    (2, 64, 16, 32), (1, 64, 13, 37), (3, 64, 40, 40), (1, 64, 5, 3)])

@@ -142,15 +142,18 @@ def test_planner_v5s_on_cpu():
     # 62 convolutions: 8 C3 (cv1, cv2) pairs fused, the first one fused with the Focus slicing and the NCHW edge, the
     # 32- and 64-channel bottlenecks (1x1 + 3x3: one in the first C3, three in the second, one in the last neck C3 at
     # 80 x 80) one kernel each, the three prediction convs decode in place
-    assert kinds[0] == "focus_conv" and kinds.count("conv") == 38 and kinds.count("bottleneck") == 4 and kinds.count("c3tail") == 1
+    # (and the Focus layer takes that first pair into its own kernel: 37 plain convolution launches remain)
+    assert kinds[0] == "focus_pair" and kinds.count("conv") == 37 and kinds.count("bottleneck") == 4 and kinds.count("c3tail") == 1
     assert kinds.count("head_decode") == 3 and "copy" not in kinds
     assert kinds.count("spp") == 1 and kinds.count("upsample") == 0      # both upsamples ride in the 1x1 convs behind them
     tail = [op for op in plan.ops if op.kind == 12][0]        # first C3: bottleneck + concat + cv3 in one kernel
     assert (tail.conv.x_ld, tail.conv.x_coff, tail.conv2.res_ld, tail.conv3.x_ld, tail.conv3.x_coff, tail.conv3.Cin,
             tail.conv3.y_ld, tail.conv3.y_coff) == (32, 0, 32, 32, 0, 64, 64, 0)
-    sib = plan.ops[1]                                         # Conv(32, 64, 3, 2) with the C3's sibling pair (cv1 | cv2) run on its
-    assert (sib.conv.KH, sib.conv.stride, sib.conv.Cin, sib.conv.Cout, sib.conv.pw_cout, sib.conv.pw_kp) == (3, 2, 32, 64, 64, 64)  # tile
-    assert (sib.conv.y_split, sib.conv.y_ld, sib.conv.y2_ld, sib.conv.y2_coff) == (32, 32, 32, 0) and sib.conv.pw_w
+    stem = plan.ops[0]       # Focus + Conv(32, 64, 3, 2) with the C3's sibling pair (cv1 | cv2) run on its tile
+    assert stem.kind == 14 and (stem.conv.Cin, stem.conv.Cout, stem.conv.kp, stem.conv.H, stem.conv.y) == (3, 32, 160, 640, None)
+    sib = stem.conv2
+    assert (sib.KH, sib.stride, sib.Cin, sib.Cout, sib.pw_cout, sib.pw_kp, sib.H, sib.Ho) == (3, 2, 32, 64, 64, 64, 320, 160)
+    assert (sib.y_split, sib.y_ld, sib.y2_ld, sib.y2_coff) == (32, 32, 32, 0) and sib.pw_w and not sib.x
     bn = [op for op in plan.ops if op.kind == 11][2]          # second C3 (64 channels): its last bottleneck writes concat half 1
     assert (bn.conv.x_ld, bn.conv.x_coff, bn.conv2.y_ld, bn.conv2.y_coff, bn.conv2.res_ld) == (64, 0, 128, 0, 64)
     gflop = sum(i["flops"] for i in plan.op_info) / 2 / 1e9

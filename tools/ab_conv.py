@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=25)
     ap.add_argument("--burst", type=int, default=8)
     ap.add_argument("--shapes", default="", help="extra shapes N,H,W,Cin,Cout,k,s,res;...")
+    ap.add_argument("--cold", type=int, default=0, help="megabytes written between timed launches (one launch per "
+                    "interval then): inside a network a layer's weights come from HBM and its input from whatever the "
+                    "layer before left in the caches, not from eight runs of itself")
     ap.add_argument("--tiles", nargs="*", default=[], help="YDET_CONV_TILE per library ('-' for none): each library reads "
                     "the variable once, at its first launch, so copies of one build can run different forced tiles")
     args = ap.parse_args()
@@ -69,6 +72,7 @@ def main():
         shapes = [tuple(int(v) for v in s.split(",")) for s in args.shapes.split(";") if s]
     if args.only:
         shapes = [shapes[int(i)] for i in args.only.split(",")]
+    flush = torch.zeros(max(args.cold, 1) * (1 << 18), device=dev) if args.cold else None
     stream = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cpu").manual_seed(1)
     print("shape".ljust(38) + "".join(f"{n:>26s}" for n, _ in libs))
@@ -107,17 +111,21 @@ def main():
         torch.cuda.synchronize()
         times = [[] for _ in libs]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        burst = 1 if args.cold else args.burst
         for rnd in range(args.rounds + 3):
             for li, (name, h) in enumerate(libs):
+                if args.cold:
+                    flush.add_(1.0)
+                    x.add_(0)             # the input as the layer before would have left it: last thing written
                 ev[0].record()
-                for _ in range(args.burst):
+                for _ in range(burst):
                     rc = h.ydet_conv2d_nhwc(ds[li], stream)
                     if rc != 0:
                         raise RuntimeError(f"{name}: {h.ydet_last_error().decode()}")
                 ev[1].record()
                 ev[1].synchronize()
                 if rnd >= 3:
-                    times[li].append(ev[0].elapsed_time(ev[1]) * 1e3 / args.burst)
+                    times[li].append(ev[0].elapsed_time(ev[1]) * 1e3 / burst)
         flop = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         line = f"{str(shp):38s}"
         for li in range(len(libs)):

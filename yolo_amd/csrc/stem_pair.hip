@@ -1,0 +1,370 @@
+// The first TWO layers of the YOLOv5 networks (plus the 1x1 pair that opens the first C3) in one pass over the NCHW
+// image (gfx950): Focus slicing + Conv(12, 32, 3, 1) + Conv(32, 64, 3, 2) [+ 1x1 follower on the 64 channels], each with
+// its folded BatchNorm and activation (yolov5s.yaml backbone rows 0-2; yolov5_official/modules.py Focus, Conv, C3).
+// Run one after the other these layers are bound by HBM: the 32-channel map at half the image size is the largest
+// tensor of the whole network (written once, read once).  Here it exists only as a 17 x 33 pixel patch in LDS.
+//
+// A workgroup (4 waves) produces an 8 x 16 patch of the second convolution's output pixels:
+//   P0  the 38 x 70 x 3 image patch underneath -> LDS focus tile F[19][35] (12 channels + 4 zeros, bf16, 48-byte pitch)
+//   P1  first convolution on the 17 x 33 patch A of ITS output pixels the second one needs (36 MFMA pixel groups of 16,
+//       K = 9 taps x 16 channels), bias + activation, bf16; pixels outside the map are the second convolution's zero padding
+//       -> LDS A (over F), even and odd columns apart so that a stride-2 tap reads 16 consecutive pixels (80-byte pitch)
+//   P2  second convolution (K = 9 taps x 32 channels) from A; waves split 2 (channels) x 2 (rows)
+//   P3  optional 1x1 follower: the finished 128 x 64 tile goes through LDS (144-byte pitch) once more
+// Every LDS pitch is an odd number of 16-byte chunks: sixteen consecutive pixels at one channel offset fall on sixteen
+// different bank groups without any swizzle, and every tap offset is an immediate.
+#include <type_traits>
+
+#include "ydet_internal.h"
+
+using namespace ydet;
+
+namespace {
+
+constexpr int T_H = 8, T_W = 16;                  // output pixels of the second convolution per workgroup
+constexpr int A_H = 2 * T_H + 1, A_W = 2 * T_W + 1;   // first-convolution pixels underneath (3x3, stride 2, pad 1)
+constexpr int A_N = A_H * A_W;                    // 561
+constexpr int A_FRAGS = (A_N + 15) / 16;          // 36 pixel groups
+constexpr int A_HALF = (A_W + 1) / 2;             // 17 even columns (then 16 odd ones) per row
+constexpr int A_ROW = 2 * A_HALF;                 // 34 pixel slots per row
+constexpr int A_PITCH = 80;                       // bytes per pixel slot (32 channels + 16)
+constexpr int F_H = A_H + 2, F_W = A_W + 2;       // focus pixels underneath (3x3, stride 1, pad 1)
+constexpr int F_N = F_H * F_W;                    // 665
+constexpr int F_PITCH = 48;                       // 16 channels + 16 bytes
+constexpr int T_PITCH = 144;                      // 64 channels + 16 bytes
+constexpr int KSTEPS0 = 5;                        // first convolution: 9 taps x 16 channels = 144 -> 160
+constexpr int LDS_BYTES = A_H * A_ROW * A_PITCH;  // 46240 >= F (31920), >= T (18432)
+static_assert(LDS_BYTES >= F_N * F_PITCH && LDS_BYTES >= T_H * T_W * T_PITCH, "the three tiles share one LDS region");
+static_assert(A_FRAGS % 4 == 0, "pixel groups split evenly over four waves");
+
+struct PairArgs {
+    const char* x;        // [N][3][H][W]
+    const char* w0;       // first convolution, packed [>=32][160] bf16 (k = tap*16 + focus channel)
+    const float* b0;
+    const char* w1;       // second convolution, packed [>=64][288] bf16 (k = tap*32 + channel)
+    const float* b1;
+    const char* pw;       // follower, packed [>=64][64] bf16, or null
+    const float* pwb;
+    char* y;
+    char* y2;
+    int N, H, W, H1, W1, Ho, Wo;
+    int cout;             // channels written per pixel (64, or the follower's)
+    int y_ld, y_coff, y2_ld, y2_coff, y_split;
+    int tiles_x, tiles_y;
+    int act0, act1;
+    float slope0, slope1;
+    int pw_rows;          // rows of pw that exist
+};
+
+template <typename TX>
+struct Pair;   // two horizontally adjacent pixels of the image
+template <>
+struct Pair<float> {
+    typedef float2 type;
+    static __device__ __forceinline__ void split(const float2& v, float& a, float& b) { a = v.x; b = v.y; }
+};
+template <>
+struct Pair<__bf16> {
+    typedef unsigned int type;
+    static __device__ __forceinline__ void split(const unsigned int& v, float& a, float& b) {
+        a = __uint_as_float(v << 16);
+        b = __uint_as_float(v & 0xffff0000u);
+    }
+};
+template <>
+struct Pair<uint8_t> {   // raw pixel values: bf16(float(v) / 255) through a 256-entry table (yolov5_official/val.py:68-69)
+    typedef unsigned short type;
+};
+
+template <bool SILU>
+__device__ __forceinline__ float act_fast(float x, float slope) {
+    if (SILU) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+    return x > 0.f ? x : x * slope;
+}
+
+// eight finished values (accumulators of MFMAs 2h and 2h+1, bias added, activated) as one 16-byte piece
+template <bool SILU>
+__device__ __forceinline__ bf16x8 finish8(const f32x4& lo, const f32x4& hi, const float* bias, float slope) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + 4);
+    const float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)act_fast<SILU>(v[e], slope);
+    return o;
+}
+
+template <typename TX, bool FOLLOW, bool SILU0, bool SILU1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void focus_pair_kernel(const PairArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    __shared__ __bf16 lut[std::is_same<TX, uint8_t>::value ? 256 : 1];
+    if constexpr (std::is_same<TX, uint8_t>::value) lut[threadIdx.x] = (__bf16)((float)threadIdx.x / 255.0f);
+    typedef typename Pair<TX>::type pair_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring patches of an image share halo: one XCD
+    const int tx = bid % a.tiles_x, ty = bid / a.tiles_x, n = blockIdx.y;
+    const int oi0 = ty * T_H, oj0 = tx * T_W;                // first output pixel
+    const int ar0 = 2 * oi0 - 1, ac0 = 2 * oj0 - 1;          // first pixel of A (in the first convolution's output map)
+    const int Y0 = 2 * (ar0 - 1), X0 = 2 * (ac0 - 1);        // first image pixel
+
+    // ---- P0: image patch -> F.  A thread builds whole focus pixels (2 x 2 image pixels x 3 channels = six 2-pixel loads)
+    constexpr int ITER = (F_N + 255) / 256;
+    pair_t px[ITER][6];
+    const TX* img = reinterpret_cast<const TX*>(a.x) + (size_t)n * 3 * a.H * a.W;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int fp = tid + 256 * it;
+        const int fy = fp / F_W, fx = fp - fy * F_W;
+        const int Y = Y0 + 2 * fy, X = X0 + 2 * fx;          // X and W are even: a pair is inside or outside as a whole
+        const bool colok = fp < F_N && (unsigned)X < (unsigned)a.W;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const bool ok = colok && (unsigned)(Y + dy) < (unsigned)a.H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                px[it][dy * 3 + c] = pair_t();
+                if (ok) px[it][dy * 3 + c] = *reinterpret_cast<const pair_t*>(img + ((size_t)c * a.H + Y + dy) * a.W + X);
+            }
+        }
+    }
+    // weights of the first convolution: lane (row = lane&15, g) holds k = 32 s + 8 g .. + 7 of one output channel; MFMA i
+    // takes channel 8 (row>>2) + 4 i + (row&3) on its row, so a lane ends up with the 8 consecutive channels 8 g .. + 7
+    bf16x8 wf[2][KSTEPS0];
+    const int wrow = 8 * (p16 >> 2) + (p16 & 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < KSTEPS0; ++s)
+            wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w0 + ((size_t)(4 * i + wrow) * (KSTEPS0 * 32) + s * 32 + g * 8) * 2);
+    if constexpr (std::is_same<TX, uint8_t>::value) __syncthreads();   // the table is complete
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int fp = tid + 256 * it;
+        if (fp >= F_N) continue;
+        __bf16 ch[12];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if constexpr (std::is_same<TX, uint8_t>::value) {
+                    ch[dy * 3 + c] = lut[px[it][dy * 3 + c] & 0xff];
+                    ch[(2 + dy) * 3 + c] = lut[px[it][dy * 3 + c] >> 8];
+                } else {
+                    float v0, v1;
+                    Pair<TX>::split(px[it][dy * 3 + c], v0, v1);
+                    ch[dy * 3 + c] = (__bf16)v0;            // focus channel (dy, dx = 0)
+                    ch[(2 + dy) * 3 + c] = (__bf16)v1;      // (dy, dx = 1)
+                }
+            }
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            lo[e] = ch[e];
+            hi[e] = e < 4 ? ch[8 + e] : (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(lds + fp * F_PITCH) = lo;
+        *reinterpret_cast<bf16x8*>(lds + fp * F_PITCH + 16) = hi;
+    }
+    __syncthreads();
+
+    // ---- P1: first convolution on the 36 pixel groups of A (wave w: groups w, w + 4, ...) ---------------------------
+    constexpr int NG = A_FRAGS / 4;
+    f32x4 acc0[NG][2];
+    int fbase[NG];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        acc0[t][0] = acc0[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int p = (wave + 4 * t) * 16 + p16;
+        p = p < A_N ? p : A_N - 1;
+        const int r = p / A_W, c = p - r * A_W;
+        fbase[t] = (r * F_W + c) * F_PITCH + (g & 1) * 16;
+    }
+#pragma unroll
+    for (int s = 0; s < KSTEPS0; ++s) {
+        const int tap = 2 * s + (g >> 1);           // K-step s covers taps 2 s and 2 s + 1; tap 9 is padding
+        const int tp = tap < 9 ? tap : 0;
+        const int kh = tp / 3, kw = tp - kh * 3;
+        const int toff = (kh * F_W + kw) * F_PITCH;
+        bf16x8 xf[NG];
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            xf[t] = *reinterpret_cast<const bf16x8*>(lds + fbase[t] + toff);
+            if (s == KSTEPS0 - 1) xf[t] = tap < 9 ? xf[t] : bf16x8{};
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc0[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][s], xf[t], acc0[t][i], 0, 0, 0);
+    }
+    // weights of the second convolution (requested here: their latency runs under the epilogue below).  Waves split
+    // 2 (channels: wn) x 2 (rows: wm); MFMA i of a wave takes channel 32 wn + 8 (row>>2) + 4 i + (row&3).
+    const int wn = wave & 1, wm = wave >> 1;
+    bf16x8 w1f[2][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            w1f[i][t] = *reinterpret_cast<const bf16x8*>(a.w1 + ((size_t)(32 * wn + 4 * i + wrow) * 288 + t * 32 + g * 8) * 2);
+    __syncthreads();     // every wave is done reading F: A may take its place
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        const int p = (wave + 4 * t) * 16 + p16;
+        const int r = p / A_W, c = p - r * A_W;
+        const bool inside = p < A_N && (unsigned)(ar0 + r) < (unsigned)a.H1 && (unsigned)(ac0 + c) < (unsigned)a.W1;
+        bf16x8 o = finish8<SILU0>(acc0[t][0], acc0[t][1], a.b0 + 8 * g, a.slope0);
+        if (!inside) o = bf16x8{};
+        if (p < A_N) *reinterpret_cast<bf16x8*>(lds + (r * A_ROW + (c & 1) * A_HALF + (c >> 1)) * A_PITCH + g * 16) = o;
+    }
+    __syncthreads();
+
+    // ---- P2: second convolution: output row 4 wm + j (j < 4), columns p16; tap (kh, kw) of pixel (oi, oj) is A pixel
+    // (2 oi + kh, 2 oj + kw) = slot (kw & 1) * 17 + oj + (kw >> 1) of that row
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* abase = lds + ((2 * 4 * wm) * A_ROW + p16) * A_PITCH + g * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int kh = t / 3, kw = t - kh * 3;
+        bf16x8 xf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            xf[j] = *reinterpret_cast<const bf16x8*>(abase + ((2 * j + kh) * A_ROW + (kw & 1) * A_HALF + (kw >> 1)) * A_PITCH);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[i][t], xf[j], acc1[i][j], 0, 0, 0);
+    }
+
+    // where a lane's 16-byte piece (channels co .. co + 7 of output pixel row 4 wm + j, column p16) goes
+    auto store_piece = [&](int j, int co, const bf16x8& o) {
+        const int oi = oi0 + 4 * wm + j, oj = oj0 + p16;
+        if (oi >= a.Ho || oj >= a.Wo || co >= a.cout) return;
+        const size_t m = ((size_t)n * a.Ho + oi) * a.Wo + oj;
+        char* dst = (a.y2 && co >= a.y_split) ? a.y2 + (m * a.y2_ld + a.y2_coff + (co - a.y_split)) * 2
+                                              : a.y + (m * a.y_ld + a.y_coff + co) * 2;
+        *reinterpret_cast<bf16x8*>(dst) = o;
+    };
+    const int co = 32 * wn + 8 * g;
+    if constexpr (!FOLLOW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store_piece(j, co, finish8<SILU1>(acc1[0][j], acc1[1][j], a.b1 + co, a.slope1));
+        return;
+    } else {
+        // ---- P3: the finished tile through LDS, then the 1x1 convolution over its 64 channels (two K-steps) ------------
+        bf16x8 pwf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 32 * wn + 4 * i + wrow;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                pwf[i][s] = bf16x8{};
+                if (row < a.pw_rows) pwf[i][s] = *reinterpret_cast<const bf16x8*>(a.pw + ((size_t)row * 64 + s * 32 + g * 8) * 2);
+            }
+        }
+        __syncthreads();     // every wave is done reading A
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<bf16x8*>(lds + ((4 * wm + j) * 16 + p16) * T_PITCH + co * 2) =
+                finish8<SILU1>(acc1[0][j], acc1[1][j], a.b1 + co, a.slope1);
+        __syncthreads();
+        f32x4 acc2[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 xf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xf[j] = *reinterpret_cast<const bf16x8*>(lds + ((4 * wm + j) * 16 + p16) * T_PITCH + (32 * s + 8 * g) * 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pwf[i][s], xf[j], acc2[i][j], 0, 0, 0);
+        }
+        if (co < a.cout) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store_piece(j, co, finish8<SILU1>(acc2[0][j], acc2[1][j], a.pwb + co, a.slope1));
+        }
+    }
+}
+
+template <typename TX, bool FOLLOW>
+void launch_acts(const PairArgs& a, dim3 grid, hipStream_t s) {
+    const bool s0 = a.act0 == YDET_ACT_SILU, s1 = a.act1 == YDET_ACT_SILU;
+    if (s0 && s1) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, true, true>), grid, dim3(256), 0, s, a);
+    else if (!s0 && !s1) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, false, false>), grid, dim3(256), 0, s, a);
+    else if (s0) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, false, true>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+int ydet_launch_focus_pair(const ydet_conv_desc* f, const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {
+    YDET_CHECK_ARG(f != nullptr && d != nullptr && f->x && f->w && f->bias && d->w && d->bias && d->y, "focus_pair: null pointer");
+    YDET_CHECK_ARG(dtype_ok(x_dtype) || x_dtype == YDET_U8, "focus_pair: bad image dtype");
+    YDET_CHECK_ARG(f->groups <= 1 && f->dilation <= 1 && d->groups <= 1 && d->dilation <= 1, "focus_pair: plain convolutions only");
+    YDET_CHECK_ARG(f->in_dtype == YDET_BF16 && d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "focus_pair: bf16 weights and output only");
+    YDET_CHECK_ARG(f->N > 0 && f->N <= 65535 && f->H > 0 && f->W > 0 && f->H % 2 == 0 && f->W % 2 == 0,
+                   "focus_pair: image %d x %d x %d", f->N, f->H, f->W);
+    YDET_CHECK_ARG(f->Cin == 3 && f->KH == 3 && f->KW == 3 && f->stride == 1 && f->pad == 1 && f->Cout == 32 && f->kp == KSTEPS0 * 32,
+                   "focus_pair: first layer must be Focus + 3x3 / stride 1 / pad 1 with 32 output channels (kp = %d)", KSTEPS0 * 32);
+    YDET_CHECK_ARG(f->res == nullptr && f->post_scale == nullptr && f->y2 == nullptr && f->pw_w == nullptr,
+                   "focus_pair: first layer: no residual / second stage / destination / follower");
+    const int H1 = f->H / 2, W1 = f->W / 2;
+    YDET_CHECK_ARG(d->N == f->N && d->H == H1 && d->W == W1 && d->Cin == 32 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 &&
+                       d->Cout == 64 && d->kp == 288 && d->cout_pad >= 64,
+                   "focus_pair: second layer must be 3x3 / stride 2 / pad 1, 32 -> 64 channels on the %d x %d map", H1, W1);
+    YDET_CHECK_ARG(d->Ho == (H1 - 1) / 2 + 1 && d->Wo == (W1 - 1) / 2 + 1, "focus_pair: second layer output %d x %d", d->Ho, d->Wo);
+    YDET_CHECK_ARG(d->res == nullptr && d->post_scale == nullptr && d->x_up == nullptr && d->cout_store == 0,
+                   "focus_pair: second layer: no residual / second stage / upsampled source / padded store");
+    const int cout = d->pw_w ? d->pw_cout : 64;
+    if (d->pw_w) YDET_CHECK_ARG(d->pw_bias && d->pw_kp == 64 && d->pw_cout >= 8 && d->pw_cout <= 64 && d->pw_cout % 8 == 0,
+                                "focus_pair: follower with %d outputs (multiple of 8, <= 64; pw_kp = 64)", d->pw_cout);
+    if (d->y2) {
+        YDET_CHECK_ARG(d->y_split > 0 && d->y_split < cout && d->y_split % 8 == 0 && d->y2_ld % 8 == 0 && d->y2_coff % 8 == 0 &&
+                           d->y2_coff >= 0 && d->y2_coff + (cout - d->y_split) <= d->y2_ld && ((uintptr_t)d->y2 & 15) == 0,
+                       "focus_pair: second destination (split, ld, coff multiples of 8)");
+    }
+    const int ny = d->y2 ? d->y_split : cout;
+    YDET_CHECK_ARG(d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && d->y_coff >= 0 && d->y_coff + ny <= d->y_ld,
+                   "focus_pair: output slice (y_ld, y_coff multiples of 8)");
+    YDET_CHECK_ARG(((uintptr_t)f->x & (x_dtype == YDET_U8 ? 1 : 7)) == 0 && ((uintptr_t)f->w & 15) == 0 && ((uintptr_t)d->w & 15) == 0 &&
+                       ((uintptr_t)d->y & 15) == 0 && ((uintptr_t)f->bias & 15) == 0 && ((uintptr_t)d->bias & 15) == 0 &&
+                       ((uintptr_t)d->pw_w & 15) == 0 && ((uintptr_t)d->pw_bias & 15) == 0,
+                   "focus_pair: pointer alignment");
+    PairArgs a;
+    a.x = (const char*)f->x; a.w0 = (const char*)f->w; a.b0 = f->bias;
+    a.w1 = (const char*)d->w; a.b1 = d->bias; a.pw = (const char*)d->pw_w; a.pwb = d->pw_bias;
+    a.y = (char*)d->y; a.y2 = (char*)d->y2;
+    a.N = f->N; a.H = f->H; a.W = f->W; a.H1 = H1; a.W1 = W1; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.cout = cout;
+    a.y_ld = d->y_ld; a.y_coff = d->y_coff; a.y2_ld = d->y2_ld; a.y2_coff = d->y2_coff; a.y_split = d->y_split;
+    a.tiles_x = (a.Wo + T_W - 1) / T_W; a.tiles_y = (a.Ho + T_H - 1) / T_H;
+    a.act0 = f->act; a.slope0 = f->act == YDET_ACT_NONE ? 1.0f : f->slope;
+    a.act1 = d->act; a.slope1 = d->act == YDET_ACT_NONE ? 1.0f : d->slope;
+    a.pw_rows = d->pw_w ? d->pw_cout : 0;
+    const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)a.N);
+    if (d->pw_w) {
+        if (x_dtype == YDET_F32) launch_acts<float, true>(a, grid, stream);
+        else if (x_dtype == YDET_U8) launch_acts<uint8_t, true>(a, grid, stream);
+        else launch_acts<__bf16, true>(a, grid, stream);
+    } else {
+        if (x_dtype == YDET_F32) launch_acts<float, false>(a, grid, stream);
+        else if (x_dtype == YDET_U8) launch_acts<uint8_t, false>(a, grid, stream);
+        else launch_acts<__bf16, false>(a, grid, stream);
+    }
+    YDET_CHECK_LAUNCH("focus_pair_kernel");
+    return YDET_OK;
+}
+
+extern "C" int ydet_focus_conv_pair_nchw(const ydet_conv_desc* focus, const ydet_conv_desc* next, int x_dtype, void* stream) {
+    clear_error();
+    return ydet_launch_focus_pair(focus, next, x_dtype, as_stream(stream));
+}

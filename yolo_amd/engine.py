@@ -520,6 +520,55 @@ class Graph:
             del self.ops[j]
             self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
 
+    # ---- Focus layer + the stride-2 convolution behind it as one kernel ---------------------------------------------------
+    def fuse_focus_pair(self):
+        """A fused Focus layer with 32 output channels whose map is read by exactly one op, a plain 3x3 / stride 2 / pad 1
+        convolution to 64 channels (on its own or carrying a 1x1 follower): both become one "focus_pair" op and the
+        32-channel map in between -- the largest tensor of a YOLOv5 forward pass -- is never written."""
+        if not _fuse_focus_pair or self.dt != _ffi.BF16:
+            return
+
+        def inputs(k, a):
+            if k in ("focus_conv", "rgb_conv", "nchw2nhwc"):
+                return []
+            if k == "nhwc2nchw":
+                return [a["x"]]
+            ts = [a[key] for key in ("x", "res", "other") if isinstance(a.get(key), T)]
+            if k in ("bottleneck", "c3tail"):
+                ts.append(a["cv1"]["x"])
+            if a.get("up") is not None:
+                ts.append(a["up"][0])
+            if a.get("pre") is not None:
+                ts = [t for t in ts if t is not a["x"]] + [a["pre"]["x"]]   # (the follower's own input no longer exists)
+            return ts
+
+        for idx, (kind, e) in enumerate(list(self.ops)):
+            if kind != "focus_conv" or e["pc"].Cout != 32:
+                continue
+            root, off = e["y"].resolve()
+            if root.external or not e["y"].whole() or any(v.resolve()[0] is root for v in self.outputs.values() if isinstance(v, T)):
+                continue
+            readers = [(k2, a2) for k2, a2 in self.ops if a2 is not e and any(t.resolve()[0] is root for t in inputs(k2, a2))]
+            if len(readers) != 1 or readers[0][0] != "conv":
+                continue
+            B = readers[0][1]
+            pre = B.get("pre")
+            pa = pre["pc"] if pre else B["pc"]
+            xa = pre["x"] if pre else B["x"]
+            sa, pda = (pre["stride"], pre["pad"]) if pre else (B["stride"], B["pad"])
+            if not (pa.plain and (pa.KH, pa.KW, sa, pda) == (3, 3, 2, 1) and pa.Cout == 64 and pa.kp == 288 and xa.resolve() == (root, off)
+                    and xa.C == 32 and B["y"].dtype == _ffi.BF16 and all(B.get(k) is None for k in ("res", "post", "up"))):
+                continue
+            if pre is None and (B.get("y2") is not None or B["y"].C != 64):
+                continue
+            if pre is not None and not (B["pc"].Cout % 8 == 0 and B["pc"].Cout <= 64 and B["pc"].kp == 64):
+                continue
+            j = next(i for i, (_, r) in enumerate(self.ops) if r is B)
+            self.ops[idx] = ("focus_pair", dict(focus=e, conv=B))
+            root.dead = True          # never written, never read: no memory behind it
+            del self.ops[j]
+            self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
+
     # ---- finalize ------------------------------------------------------------------------------
     def finalize(self, replicas=1):
         return Plan(self, replicas)
@@ -540,6 +589,7 @@ class Plan:
         g.fuse_upsamples()
         g.fuse_pointwise_followers()
         g.fuse_rgb_stem()
+        g.fuse_focus_pair()
         n = len(g.ops)
         self.patch_in = list(g.ext_in)  # op indices whose source is a caller-supplied NCHW input
         self.patch_out = []       # (op index, field, storage) of external NHWC buffers
@@ -551,7 +601,7 @@ class Plan:
             arena = {}
             for st in g.storages:
                 root, _ = st.root()
-                if root is st and not st.external:
+                if root is st and not st.external and not getattr(st, "dead", False):
                     arena[st] = torch.empty(st.N, st.H, st.W, st.ld, device=g.device, dtype=_TORCH_DT[st.dtype])
             self.arenas.append(arena)
             ops = (_ffi.Op * n)()
@@ -570,7 +620,7 @@ class Plan:
             return 0
         return arena[root].data_ptr()
 
-    def _fill(self, op, i, kind, a, arena, record):
+    def _fill(self, op, i, kind, a, arena, record, with_y=True):
         if kind == "conv":
             self._fill_conv(op, i, a, arena, record)
         elif kind == "bottleneck":
@@ -601,11 +651,17 @@ class Plan:
             hd.grid_transposed, hd.stride = a["transposed"], a["det_stride"]
             for k, v in enumerate(a["anchors"]):
                 hd.anchor_wh[k] = v
+        elif kind == "focus_pair":
+            assert not a["conv"]["y"].resolve()[0].external
+            self._fill_conv(op, i, a["conv"], arena, record, d=op.conv2, skip_x=True)
+            self._fill(op, i, "focus_conv", a["focus"], arena, record, with_y=False)
+            op.kind = _ffi.OP_FOCUS_PAIR
         elif kind in ("focus_conv", "rgb_conv"):
             op.kind = _ffi.OP_FOCUS_CONV if kind == "focus_conv" else _ffi.OP_RGB_CONV
             d, pc = op.conv, a["pc"]
             root, off = a["y"].resolve()
-            d.y, d.w, d.bias = self._ptr(root, arena, i, "cy", record), pc.w.data_ptr(), pc.b.data_ptr()
+            d.y = self._ptr(root, arena, i, "cy", record) if with_y else 0
+            d.w, d.bias = pc.w.data_ptr(), pc.b.data_ptr()
             d.N, d.H, d.W, d.Cin = a["N"], a["H"], a["W"], a["C"]
             d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, 3, 3, 1, 1
             d.Ho, d.Wo = (a["H"] // 2, a["W"] // 2) if kind == "focus_conv" else (a["H"], a["W"])
@@ -645,13 +701,13 @@ class Plan:
             sl.N, sl.H, sl.W, sl.C = x.N, x.H, x.W, x.C
             sl.x_ld, sl.x_coff, sl.y_ld, sl.y_coff, sl.dtype = rx.ld, ox, ry.ld, oy, rx.dtype
 
-    def _fill_conv(self, op, i, a, arena, record, d=None):
+    def _fill_conv(self, op, i, a, arena, record, d=None, skip_x=False):
         op.kind = _ffi.OP_CONV
         d = op.conv if d is None else d
         x, y, res, pc = a["x"], a["y"], a["res"], a["pc"]
         rx, ox = x.resolve()
         ry, oy = y.resolve()
-        d.x = self._ptr(rx, arena, i, "cx", record)
+        d.x = 0 if skip_x else self._ptr(rx, arena, i, "cx", record)
         d.y = self._ptr(ry, arena, i, "cy", record)
         d.w, d.bias = pc.w.data_ptr(), pc.b.data_ptr()
         d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
@@ -674,7 +730,7 @@ class Plan:
             pre = a["pre"]
             p1, x1 = pre["pc"], pre["x"]
             r1, o1 = x1.resolve()
-            d.x = self._ptr(r1, arena, i, "cx", record)
+            d.x = 0 if skip_x else self._ptr(r1, arena, i, "cx", record)
             d.w, d.bias = p1.w.data_ptr(), p1.b.data_ptr()
             d.H, d.W, d.Cin, d.x_ld, d.x_coff = x1.H, x1.W, x1.C, r1.ld, o1
             d.Cout, d.KH, d.KW, d.stride, d.pad = p1.Cout, p1.KH, p1.KW, pre["stride"], pre["pad"]
@@ -710,11 +766,11 @@ class Plan:
                for st in self._ext_storages}
         for i, x in zip(self.patch_in, xs):
             op0 = self.op_lists[0][i]
-            focus = op0.kind in (_ffi.OP_FOCUS_CONV, _ffi.OP_RGB_CONV)      # first layers that read the image themselves
+            focus = op0.kind in (_ffi.OP_FOCUS_CONV, _ffi.OP_RGB_CONV, _ffi.OP_FOCUS_PAIR)   # first layers that read the image themselves
             if x.dtype == torch.uint8:
                 # raw pixel values: the fused Focus layer scales them by 1/255 while loading (val.py:68-69 folded in);
                 # any other first layer gets the scaled fp32 image
-                if op0.kind != _ffi.OP_FOCUS_CONV:
+                if op0.kind not in (_ffi.OP_FOCUS_CONV, _ffi.OP_FOCUS_PAIR):
                     x = x.float() / 255.0
             elif x.dtype not in (torch.float32, torch.bfloat16):
                 x = x.float()
@@ -779,6 +835,14 @@ class Plan:
 _batch_split = 1
 _fuse_upsample = True
 _fuse_followers = True
+_fuse_focus_pair = True
+
+
+def set_focus_pair_fusion(flag):
+    """Whether plans run the Focus layer and the stride-2 convolution behind it as one kernel (default on).  Off: two
+    launches with the 32-channel half-size map written and read back (ablation / comparison)."""
+    global _fuse_focus_pair
+    _fuse_focus_pair = bool(flag)
 
 
 def set_follower_fusion(flag):
@@ -898,6 +962,16 @@ def _op_info(kind, a):
         return dict(kind="conv", label="conv_rgb3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 27,
                     bytes=a["N"] * 3 * a["H"] * a["W"] * 4 + y.N * y.H * y.W * y.C * esz(y),
                     shape=(a["N"], a["H"], a["W"], 3, pc.Cout, 3, 1))
+    if kind == "focus_pair":
+        f, B = a["focus"], a["conv"]
+        pre, y = B.get("pre"), B["y"]
+        pa = pre["pc"] if pre else B["pc"]
+        px1, px2 = f["N"] * (f["H"] // 2) * (f["W"] // 2), y.N * y.H * y.W
+        cout = B["pc"].Cout
+        flops = 2.0 * px1 * 32 * 4 * f["C"] * 9 + 2.0 * px2 * 64 * 32 * 9 + (2.0 * px2 * cout * 64 if pre else 0.0)
+        nbytes = f["N"] * f["C"] * f["H"] * f["W"] * 4 + px2 * cout * 2 + (32 * 160 + 64 * 288 + (cout * 64 if pre else 0)) * 2
+        return dict(kind="conv", label="conv_focus_pair", flops=flops, bytes=nbytes,
+                    shape=(f["N"], f["H"], f["W"], f["C"], cout, 3, 4))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
         return dict(kind="conv", label="conv_focus3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
