@@ -82,11 +82,10 @@ __device__ __forceinline__ float act_fast(float x, float slope) {
     return x > 0.f ? x : x * slope;
 }
 
-// eight finished values (accumulators of MFMAs 2h and 2h+1, bias added, activated) as one 16-byte piece
+// eight finished values (accumulators of MFMAs 2h and 2h+1, bias added, activated) as one 16-byte piece.  (Starting
+// the accumulators from the bias instead costs a register move each; zero accumulators are an inline constant.)
 template <bool SILU>
-__device__ __forceinline__ bf16x8 finish8(const f32x4& lo, const f32x4& hi, const float* bias, float slope) {
-    const float4 b0 = *reinterpret_cast<const float4*>(bias);
-    const float4 b1 = *reinterpret_cast<const float4*>(bias + 4);
+__device__ __forceinline__ bf16x8 finish8(const f32x4& lo, const f32x4& hi, const float4& b0, const float4& b1, float slope) {
     const float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
     bf16x8 o;
 #pragma unroll
@@ -113,19 +112,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     constexpr int ITER = (F_N + 255) / 256;
     pair_t px[ITER][6];
     const TX* img = reinterpret_cast<const TX*>(a.x) + (size_t)n * 3 * a.H * a.W;
+    // (offsets inside one image fit 32 bits -- checked on the host -- and the image base is uniform)
+    const bool interior0 = Y0 >= 0 && Y0 + 2 * F_H <= a.H && X0 >= 0 && X0 + 2 * F_W <= a.W;   // workgroup-uniform
+    if (interior0) {
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int fp = tid + 256 * it;
-        const int fy = fp / F_W, fx = fp - fy * F_W;
-        const int Y = Y0 + 2 * fy, X = X0 + 2 * fx;          // X and W are even: a pair is inside or outside as a whole
-        const bool colok = fp < F_N && (unsigned)X < (unsigned)a.W;
+        for (int it = 0; it < ITER; ++it) {
+            const int fp = min(tid + 256 * it, F_N - 1);
+            const int fy = fp / F_W, fx = fp - fy * F_W;
+            const unsigned o0 = (unsigned)((Y0 + 2 * fy) * a.W + X0 + 2 * fx), plane = (unsigned)(a.H * a.W);
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            const bool ok = colok && (unsigned)(Y + dy) < (unsigned)a.H;
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                px[it][dy * 3 + c] = pair_t();
-                if (ok) px[it][dy * 3 + c] = *reinterpret_cast<const pair_t*>(img + ((size_t)c * a.H + Y + dy) * a.W + X);
+                for (int c = 0; c < 3; ++c)
+                    px[it][dy * 3 + c] = *reinterpret_cast<const pair_t*>(img + (o0 + (unsigned)c * plane + (unsigned)dy * (unsigned)a.W));
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int fp = tid + 256 * it;
+            const int fy = fp / F_W, fx = fp - fy * F_W;
+            const int Y = Y0 + 2 * fy, X = X0 + 2 * fx;          // X and W are even: a pair is inside or outside as a whole
+            const bool colok = fp < F_N && (unsigned)X < (unsigned)a.W;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const bool ok = colok && (unsigned)(Y + dy) < (unsigned)a.H;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    px[it][dy * 3 + c] = pair_t();
+                    if (ok) px[it][dy * 3 + c] = *reinterpret_cast<const pair_t*>(img + ((unsigned)(c * a.H + Y + dy) * (unsigned)a.W + (unsigned)X));
+                }
             }
         }
     }
@@ -138,6 +153,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int s = 0; s < KSTEPS0; ++s)
             wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w0 + ((size_t)(4 * i + wrow) * (KSTEPS0 * 32) + s * 32 + g * 8) * 2);
+    // the second half of the last K-step is padding ("tap 9"): zero weights there, whatever the packed rows hold, so the
+    // pixel operand of those lanes may be any finite values
+    if (g >= 2) wf[0][KSTEPS0 - 1] = wf[1][KSTEPS0 - 1] = bf16x8{};
     if constexpr (std::is_same<TX, uint8_t>::value) __syncthreads();   // the table is complete
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -190,8 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         bf16x8 xf[NG];
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
-            xf[t] = *reinterpret_cast<const bf16x8*>(lds + fbase[t] + toff);
-            if (s == KSTEPS0 - 1) xf[t] = tap < 9 ? xf[t] : bf16x8{};
+            xf[t] = *reinterpret_cast<const bf16x8*>(lds + fbase[t] + toff);   // (tap 9: finite values times zero weights)
         }
 #pragma unroll
         for (int t = 0; t < NG; ++t)
@@ -208,13 +225,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int t = 0; t < 9; ++t)
             w1f[i][t] = *reinterpret_cast<const bf16x8*>(a.w1 + ((size_t)(32 * wn + 4 * i + wrow) * 288 + t * 32 + g * 8) * 2);
     __syncthreads();     // every wave is done reading F: A may take its place
+    // pixels of A outside the map are the second convolution's zero padding (border workgroups only)
+    const float4 b0lo = *reinterpret_cast<const float4*>(a.b0 + 8 * g), b0hi = *reinterpret_cast<const float4*>(a.b0 + 8 * g + 4);
+    const bool interior1 = ar0 >= 0 && ar0 + A_H <= a.H1 && ac0 >= 0 && ac0 + A_W <= a.W1;     // workgroup-uniform
 #pragma unroll
     for (int t = 0; t < NG; ++t) {
         const int p = (wave + 4 * t) * 16 + p16;
         const int r = p / A_W, c = p - r * A_W;
-        const bool inside = p < A_N && (unsigned)(ar0 + r) < (unsigned)a.H1 && (unsigned)(ac0 + c) < (unsigned)a.W1;
-        bf16x8 o = finish8<SILU0>(acc0[t][0], acc0[t][1], a.b0 + 8 * g, a.slope0);
-        if (!inside) o = bf16x8{};
+        bf16x8 o = finish8<SILU0>(acc0[t][0], acc0[t][1], b0lo, b0hi, a.slope0);
+        if (!interior1 && !((unsigned)(ar0 + r) < (unsigned)a.H1 && (unsigned)(ac0 + c) < (unsigned)a.W1)) o = bf16x8{};
         if (p < A_N) *reinterpret_cast<bf16x8*>(lds + (r * A_ROW + (c & 1) * A_HALF + (c >> 1)) * A_PITCH + g * 16) = o;
     }
     __syncthreads();
@@ -250,9 +269,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         *reinterpret_cast<bf16x8*>(dst) = o;
     };
     const int co = 32 * wn + 8 * g;
+    const float4 b1lo = *reinterpret_cast<const float4*>(a.b1 + co), b1hi = *reinterpret_cast<const float4*>(a.b1 + co + 4);
     if constexpr (!FOLLOW) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) store_piece(j, co, finish8<SILU1>(acc1[0][j], acc1[1][j], a.b1 + co, a.slope1));
+        for (int j = 0; j < 4; ++j) store_piece(j, co, finish8<SILU1>(acc1[0][j], acc1[1][j], b1lo, b1hi, a.slope1));
         return;
     } else {
         // ---- P3: the finished tile through LDS, then the 1x1 convolution over its 64 channels (two K-steps) ------------
@@ -270,7 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<bf16x8*>(lds + ((4 * wm + j) * 16 + p16) * T_PITCH + co * 2) =
-                finish8<SILU1>(acc1[0][j], acc1[1][j], a.b1 + co, a.slope1);
+                finish8<SILU1>(acc1[0][j], acc1[1][j], b1lo, b1hi, a.slope1);
         __syncthreads();
         f32x4 acc2[2][4];
 #pragma unroll
@@ -289,8 +309,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pwf[i][s], xf[j], acc2[i][j], 0, 0, 0);
         }
         if (co < a.cout) {
+            const float4 plo = *reinterpret_cast<const float4*>(a.pwb + co), phi = *reinterpret_cast<const float4*>(a.pwb + co + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) store_piece(j, co, finish8<SILU1>(acc2[0][j], acc2[1][j], a.pwb + co, a.slope1));
+            for (int j = 0; j < 4; ++j) store_piece(j, co, finish8<SILU1>(acc2[0][j], acc2[1][j], plo, phi, a.slope1));
         }
     }
 }
@@ -317,6 +338,7 @@ int ydet_launch_focus_pair(const ydet_conv_desc* f, const ydet_conv_desc* d, int
                    "focus_pair: first layer must be Focus + 3x3 / stride 1 / pad 1 with 32 output channels (kp = %d)", KSTEPS0 * 32);
     YDET_CHECK_ARG(f->res == nullptr && f->post_scale == nullptr && f->y2 == nullptr && f->pw_w == nullptr,
                    "focus_pair: first layer: no residual / second stage / destination / follower");
+    YDET_CHECK_ARG(3LL * f->H * f->W < (1LL << 31), "focus_pair: image of %d x %d pixels", f->H, f->W);
     const int H1 = f->H / 2, W1 = f->W / 2;
     YDET_CHECK_ARG(d->N == f->N && d->H == H1 && d->W == W1 && d->Cin == 32 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 &&
                        d->Cout == 64 && d->kp == 288 && d->cout_pad >= 64,
