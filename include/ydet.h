@@ -238,8 +238,10 @@ int ydet_decode_v5(const ydet_v5_level* levels /* host */, int nl, int N, int na
 
 /* One pyramid level of Detect as ONE kernel: the bias-only 1x1 prediction convolution (yolov5_official/model.py:42,58
  * `self.m[i]`) with the eval-mode decode of lines 56-81 in its epilogue.  `d` describes the convolution
- * (1x1, fp32 output, no activation, Cout = na*no <= 256, weights padded to 256 rows); its output d->y is the raw map
- * the reference returns as x[i] (NHWC, channel a*no + o).  The decoded rows go to z [N, rows_per_image, no] at rows
+ * (1x1, no activation, Cout = na*no <= 256, weights padded to 256 rows); its output d->y is the raw map
+ * the reference returns as x[i] (NHWC, channel a*no + o): fp32, or -- with bf16 inputs -- bf16 (out_dtype), the
+ * counterpart of the half-precision x[i] a `model.half()` reference returns; z and row_max are computed from the fp32
+ * accumulators either way.  The decoded rows go to z [N, rows_per_image, no] (fp32) at rows
  * level_row_offset + (a*ny + row)*nx + col, and max_c(z[5+c] * z[4]) per row to row_max (may be NULL) -- exactly what
  * ydet_decode_v5 would produce from d->y.  no <= 128. */
 typedef struct {

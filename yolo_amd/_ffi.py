@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libydet.so")
+# YDET_LIB=<path>: another build of the library (A/B timing of kernel variants; the ABI check below still applies)
+LIB_PATH = os.environ.get("YDET_LIB") or os.path.join(_HERE, "libydet.so")
 
 F32, BF16, U8 = 0, 1, 2   # U8: output dtype of ydet_preprocess_u8 only
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2

@@ -310,8 +310,8 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     // rows (fragment i, MFMA row r = 4 q + e) takes channel 32 (i>>1) + 8 q + 4 (i&1) + e: the accumulator rows a lane
     // ends up with in fragments 2 s and 2 s + 1 are then EIGHT CONSECUTIVE channels (one 16-byte piece), and the four
     // lane groups q of a pixel hold 64 consecutive bytes of it, so the epilogue stores straight from registers.  fp32
-    // outputs keep the natural order (a fragment's four rows are a 16-byte piece already), so does the decoding head.
-    constexpr bool PERM = !HEAD && sizeof(TOUT) == 2;
+    // outputs keep the natural order (a fragment's four rows are a 16-byte piece already).
+    constexpr bool PERM = sizeof(TOUT) == 2;
     const char* wsrc[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
@@ -580,78 +580,71 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
             }
             pix_row[tid] = row; pix_gx[tid] = gx; pix_gy[tid] = gy;
         }
-        // (1) accumulators + bias -> tile, pixel-major
-        auto stage_tile = [&](auto squash) {
-#pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                const int pl = wm * WM + j * 16 + px;
-#pragma unroll
-                for (int i = 0; i < FN; ++i) {
-                    const int cl = wn * WN + i * 16 + q * 4;
-                    const float4 b = *reinterpret_cast<const float4*>(cst + cl);
-                    float4 v = make_float4(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
-                    if (decltype(squash)::value)
-                        v = make_float4(sigmoid_fast(v.x), sigmoid_fast(v.y), sigmoid_fast(v.z), sigmoid_fast(v.w));
-                    *reinterpret_cast<float4*>(stage + pl * HEAD_RP + cl) = v;
-                }
-            }
-        };
-        YDET_STAMP(20);
-        stage_tile(std::false_type{});
-        __syncthreads();
-        YDET_STAMP(21);
-        // (2) the raw prediction map, whole 16-byte pieces
-        constexpr int PIECES = BN / 4;
-        static_assert(BM * PIECES % NT == 0, "whole pieces per thread");
-        {
-            float4 piece_v[BM * PIECES / NT];
-#pragma unroll
-            for (int k = 0; k < BM * PIECES / NT; ++k) {      // all LDS reads first, then the stores
-                const int idx = tid + k * NT;
-                piece_v[k] = *reinterpret_cast<const float4*>(stage + (idx / PIECES) * HEAD_RP + (idx % PIECES) * 4);
-            }
-#pragma unroll
-            for (int k = 0; k < BM * PIECES / NT; ++k) {
-                const int idx = tid + k * NT;
-                const int pl = idx / PIECES, piece = idx % PIECES;
-                const long long m = m0 + pl;
-                const int co = n0 + piece * 4;
-#ifdef YDET_EXP_NO_RAWST
-                if (m < a.M && co < a.cout_store && piece_v[k].x == 12345.678f)
-#else
-                if (m < a.M && co < a.cout_store)
-#endif
-                    __builtin_nontemporal_store(f32x4{piece_v[k].x, piece_v[k].y, piece_v[k].z, piece_v[k].w},
-                                                reinterpret_cast<f32x4*>(a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(float)));
-            }
-        }
-        __syncthreads();
-        YDET_STAMP(22);
-        // (3) sigmoid of every value, taken where the tile sits in registers with all lanes busy, and laid down in the
-        // order of the decoded rows: zt[anchor][pixel][column], so each anchor's part of the tile is one run of z
+        // (1) The raw prediction map straight from registers, and the sigmoid of every value laid down in LDS in the
+        // order of the decoded rows: zt[anchor][pixel][column], so each anchor's part of the tile is one run of z.
+        // A lane holds channels chan(i) .. + 3 of its pixels in fragment i (with bf16 raw maps the weight rows are permuted
+        // so that fragments 2 s and 2 s + 1 together are the EIGHT consecutive channels of one 16-byte piece); where
+        // each of those sixteen channels lands inside an anchor's rows is worked out once per lane, not per value.
+        // Pad channels (na * no .. 255) land in four spare floats behind the last anchor, whatever the pixel (their pixel
+        // stride is zero).
         float* zt = stage;
         const int per_an = BM * h.no;                                // floats per anchor
+        static_assert(FN % 2 == 0, "fragments pair up");
+        auto chan = [&](int i) { return wn * WN + (PERM ? 32 * (i >> 1) + 8 * q + 4 * (i & 1) : 16 * i + 4 * q); };
+        int zoff[FN][4], zmul[FN][4];       // value (i, e) of pixel pl goes to zt[zoff + pl * zmul]
         {
             const float rno = 1.0f / (float)h.no;
+            const int dump = h.na * per_an;        // (< BM * HEAD_RP: the tile region holds BM * 260 floats, z at most BM * 256)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                const int pl = wm * WM + j * 16 + px;
+            for (int i = 0; i < FN; ++i) {
+                const int c0 = chan(i);
+                int an = div_small(c0, h.no, rno), o = c0 - an * h.no;
 #pragma unroll
-                for (int i = 0; i < FN; ++i) {
-                    const int cl = wn * WN + i * 16 + q * 4;
-                    const float4 b = *reinterpret_cast<const float4*>(cst + cl);
-                    const float v[4] = {sigmoid_fast(acc[i][j][0] + b.x), sigmoid_fast(acc[i][j][1] + b.y),
-                                        sigmoid_fast(acc[i][j][2] + b.z), sigmoid_fast(acc[i][j][3] + b.w)};
-                    int an = div_small(cl, h.no, rno), o = cl - an * h.no;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (an < h.na) zt[an * per_an + pl * h.no + o] = v[e];
-                        const bool wrap = o + 1 == h.no;
-                        o = wrap ? 0 : o + 1;
-                        an += wrap ? 1 : 0;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    zoff[i][e] = an < h.na ? an * per_an + o : dump + e;
+                    zmul[i][e] = an < h.na ? h.no : 0;
+                    const bool wrap = o + 1 == h.no;
+                    o = wrap ? 0 : o + 1;
+                    an += wrap ? 1 : 0;
                 }
             }
+        }
+        YDET_STAMP(20);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int pl = wm * WM + j * 16 + px;
+            const long long m = m0 + pl;
+            const bool okm = m < a.M;
+            char* yrow = a.y + ((size_t)(okm ? m : 0) * a.y_ld + a.y_coff + n0) * sizeof(TOUT);
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const float4 b = *reinterpret_cast<const float4*>(cst + chan(i));
+                acc[i][j][0] += b.x; acc[i][j][1] += b.y; acc[i][j][2] += b.z; acc[i][j][3] += b.w;
+            }
+#ifndef YDET_EXP_NO_RAWST
+            if constexpr (PERM) {
+#pragma unroll
+                for (int sp = 0; sp < FN / 2; ++sp) {
+                    const int c0 = chan(2 * sp);
+                    const bf16x8 t = {(__bf16)acc[2 * sp][j][0], (__bf16)acc[2 * sp][j][1], (__bf16)acc[2 * sp][j][2], (__bf16)acc[2 * sp][j][3],
+                                      (__bf16)acc[2 * sp + 1][j][0], (__bf16)acc[2 * sp + 1][j][1], (__bf16)acc[2 * sp + 1][j][2],
+                                      (__bf16)acc[2 * sp + 1][j][3]};
+                    if (okm && n0 + c0 < a.cout_store) __builtin_nontemporal_store(t, reinterpret_cast<bf16x8*>(yrow + c0 * 2));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const int c0 = chan(i);
+                    if (okm && n0 + c0 < a.cout_store)
+                        __builtin_nontemporal_store(f32x4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]},
+                                                    reinterpret_cast<f32x4*>(yrow + c0 * sizeof(TOUT)));
+                }
+            }
+#endif
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zt[zoff[i][e] + pl * zmul[i][e]] = sigmoid_fast(acc[i][j][e]);
         }
         if (tid < 16) anc[tid] = h.anchor[tid];
         __syncthreads();
@@ -1122,7 +1115,7 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
 
 // 1x1 prediction convolution of one pyramid level + Detect decode in its epilogue: 256-channel x 64-pixel tiles, so a
 // workgroup owns every channel of its pixels.
-template <typename TIN>
+template <typename TIN, typename TRAW>
 static int launch_head(const ConvArgs& a0, const HeadArgs& h, hipStream_t stream) {
     constexpr int BN = 256, BM = 64, BK = 64 / (int)sizeof(TIN);
     ConvArgs a = a0;
@@ -1133,10 +1126,10 @@ static int launch_head(const ConvArgs& a0, const HeadArgs& h, hipStream_t stream
     const int ring = 3 * (BN + BM) * 64, tile = BM * (BN + 4) * 4;
     const int lds = (tile > ring ? tile : ring) + 3 * BN * (int)sizeof(float) + 3 * BM * 4 + 16 * 4;
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_dma_kernel<TIN, float, BN, BM, 4, 1, true>),
+        reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TRAW, BN, BM, 4, 1, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "head_conv_decode: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL((conv_dma_kernel<TIN, float, BN, BM, 4, 1, true>), dim3((unsigned)nblk), dim3(256), lds, stream, a, h);
+    hipLaunchKernelGGL((conv_dma_kernel<TIN, TRAW, BN, BM, 4, 1, true>), dim3((unsigned)nblk), dim3(256), lds, stream, a, h);
     YDET_CHECK_LAUNCH("conv_dma_kernel<head>");
     return YDET_OK;
 }
@@ -1150,12 +1143,14 @@ int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, h
     const int bk = d->in_dtype == YDET_BF16 ? 32 : 16;
     YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % bk == 0,
                    "head_conv_decode: a 1x1 convolution with Cin a multiple of %d", bk);
-    YDET_CHECK_ARG(d->out_dtype == YDET_F32 && d->act == YDET_ACT_NONE && d->res == nullptr && d->post_scale == nullptr,
-                   "head_conv_decode: plain fp32 prediction map expected");
+    YDET_CHECK_ARG((d->out_dtype == YDET_F32 || d->in_dtype == YDET_BF16) && d->act == YDET_ACT_NONE && d->res == nullptr &&
+                       d->post_scale == nullptr,
+                   "head_conv_decode: plain prediction map expected (fp32, or bf16 with bf16 inputs)");
     YDET_CHECK_ARG(hd->na >= 1 && hd->na <= 8 && hd->no >= 5 && hd->no <= 128 && hd->na * hd->no == d->Cout && d->Cout <= 256,
                    "head_conv_decode: na=%d no=%d Cout=%d (na*no = Cout <= 256, no <= 128)", hd->na, hd->no, d->Cout);
-    YDET_CHECK_ARG(d->cout_pad >= 256 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0 && a.cout_store % 4 == 0,
-                   "head_conv_decode: weights padded to 256 rows and a 4-aligned output slice");
+    const int pc = d->out_dtype == YDET_BF16 ? 8 : 4;     // channels per 16-byte piece of the raw map
+    YDET_CHECK_ARG(d->cout_pad >= 256 && d->y_ld % pc == 0 && d->y_coff % pc == 0 && a.cout_store % pc == 0,
+                   "head_conv_decode: weights padded to 256 rows and a %d-aligned output slice", pc);
     YDET_CHECK_ARG(hd->ny == d->Ho && hd->nx == d->Wo && (long long)hd->ny * hd->nx < (1 << 22) &&
                        (long long)hd->ny * hd->nx * d->Cout < (1ll << 31), "head_conv_decode: map size");
     YDET_CHECK_ARG(hd->rows_per_image >= (long long)hd->level_row_offset + (long long)hd->na * hd->ny * hd->nx &&
@@ -1168,7 +1163,8 @@ int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, h
     h.stride = hd->stride;
     h.rd = 1.0f / (float)(h.transposed ? hd->ny : hd->nx);
     for (int i = 0; i < 16; ++i) h.anchor[i] = i < 2 * hd->na ? hd->anchor_wh[i] : 0.f;
-    return d->in_dtype == YDET_BF16 ? launch_head<__bf16>(a, h, stream) : launch_head<float>(a, h, stream);
+    if (d->in_dtype != YDET_BF16) return launch_head<float, float>(a, h, stream);
+    return d->out_dtype == YDET_BF16 ? launch_head<__bf16, __bf16>(a, h, stream) : launch_head<__bf16, float>(a, h, stream);
 }
 
 extern "C" int ydet_head_conv_decode(const ydet_conv_desc* d, const ydet_head_desc* head, void* stream) {

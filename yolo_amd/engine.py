@@ -315,7 +315,9 @@ class Graph:
 
     def head_decode(self, x, conv, z, row_max, level_off, na, no, stride, anchors, transposed):
         """1x1 prediction conv of one Detect level with the decode in its epilogue.  z / row_max: external storages
-        [N,1,rows,no] / [N,1,rows,1] shared by the levels; returns the raw fp32 head map (external, 256-padded)."""
+        [N,1,rows,no] / [N,1,rows,1] shared by the levels; returns the raw head map (external, 256-padded): fp32, or
+        in the plan's compute dtype when set_head_raw_dtype("compute") is in force (the default; a `model.half()`
+        reference returns half-precision x[i] as well).  z is decoded from the fp32 accumulators either way."""
         pc = pack_conv(conv, None, None, cin_phys=x.C, dtype=self.dt, device=self.device)
         if pc.cout_pad < 256:      # the kernel's weight tile is 256 rows
             wp = torch.zeros(256, pc.kp, device=self.device, dtype=pc.w.dtype)
@@ -324,7 +326,7 @@ class Graph:
             bp[:pc.cout_pad] = pc.b
             pc = PackedConv(wp, bp, pc.Cin, pc.Cout, pc.KH, pc.KW, pc.kp, 256, cin_real=pc.cin_real)
         self.keep.append(pc)
-        out = self.new(x.N, x.H, x.W, pc.Cout, dtype=_ffi.F32, external=True)
+        out = self.new(x.N, x.H, x.W, pc.Cout, dtype=self.dt if _head_raw_compute else _ffi.F32, external=True)
         self.ops.append(("head_decode", dict(x=x, y=out, res=None, pc=pc, stride=1, pad=0, act=_ffi.ACT_NONE, slope=0.0,
                                              res_mode=_ffi.RES_NONE, post=None, z=z, row_max=row_max, level_off=level_off,
                                              na=na, no=no, det_stride=float(stride), anchors=[float(v) for v in anchors],
@@ -836,6 +838,7 @@ _batch_split = 1
 _fuse_upsample = True
 _fuse_followers = True
 _fuse_focus_pair = True
+_head_raw_compute = True
 
 
 def set_focus_pair_fusion(flag):
@@ -843,6 +846,14 @@ def set_focus_pair_fusion(flag):
     launches with the 32-channel half-size map written and read back (ablation / comparison)."""
     global _fuse_focus_pair
     _fuse_focus_pair = bool(flag)
+
+
+def set_head_raw_dtype(mode):
+    """Dtype of the raw prediction maps a fused Detect level returns next to the decoded rows: "compute" (default; bf16
+    plans return bf16 maps, half the bytes of the largest stores of the forward pass) or "fp32"."""
+    global _head_raw_compute
+    assert mode in ("compute", "fp32")
+    _head_raw_compute = mode == "compute"
 
 
 def set_follower_fusion(flag):
@@ -920,7 +931,7 @@ def _op_info(kind, a):
     if kind == "head_decode":
         x, y, pc = a["x"], a["y"], a["pc"]
         flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.cin_real
-        nbytes = (x.N * x.H * x.W * x.C * esz(x) + pc.Cout * x.C * esz(x) + y.N * y.H * y.W * 256 * 4
+        nbytes = (x.N * x.H * x.W * x.C * esz(x) + pc.Cout * x.C * esz(x) + y.N * y.H * y.W * 256 * esz(y)
                   + y.N * y.H * y.W * pc.Cout * 4)
         return dict(kind="conv", label="conv_head_decode", flops=flops, bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, 1, 1))
