@@ -37,7 +37,7 @@ def label_of(name):
         return f"conv_generic<{bn}x{bm},{'1x1' if one else 'kxk'},{dts}>"
     if "bottleneck_c32" in name and ("kernel<true" in name or "ILb1E" in name):
         return "conv_c3_tail_c32"
-    for key, lab in (("focus_conv3x3", "conv_focus3x3"), ("bottleneck_c32", "conv_bottleneck_c32"), ("bottleneck_c64", "conv_bottleneck_c64"), ("decode_v5", "decode_v5"), ("v5_pick", "nms_v5_pick"),
+    for key, lab in (("focus_pair", "conv_focus_pair"), ("focus_conv3x3", "conv_focus3x3"), ("bottleneck_c32", "conv_bottleneck_c32"), ("bottleneck_c64", "conv_bottleneck_c64"), ("decode_v5", "decode_v5"), ("v5_pick", "nms_v5_pick"),
                      ("v5_nms", "nms_v5_greedy"), ("v5_rank", "nms_v5_rank"), ("v5_rowmax", "nms_v5_rowmax"),
                      ("v5_exact", "nms_v5_exact_select"), ("spp_lds", "spp"), ("upsample2x", "upsample"),
                      ("nchw_to_nhwc", "nchw2nhwc")):
@@ -107,6 +107,15 @@ def counters(paths):
             d["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
         if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in d:
             d["mfma_flops"] = d["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0
+        # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* tick once per four shader cycles: as fractions of the SIMD-cycles
+        # of the launch (waves_per_simd: average number of waves resident on a SIMD while the launch was active)
+        if d.get("GRBM_GUI_ACTIVE"):
+            simd_cycles = d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+            for c, key in (("SQ_ACTIVE_INST_VALU", "valu_active_frac"), ("SQ_ACTIVE_INST_LDS", "lds_inst_active_frac"),
+                           ("SQ_ACTIVE_INST_VMEM", "vmem_inst_active_frac"), ("SQ_ACTIVE_INST_ANY", "any_inst_active_frac"),
+                           ("SQ_WAVE_CYCLES", "waves_per_simd")):
+                if c in d:
+                    d[key] = round(d[c] * 4.0 / simd_cycles, 4)
     print(json.dumps(dict(source="rocprofv3 --pmc passes of `bench.py --no-cpu --streams 1` (counters only, no trace in the same "
                                  "run); means per launch; GRBM_GUI_ACTIVE is the sum over the 8 XCDs", kernels=agg), indent=1))
 
