@@ -240,7 +240,7 @@ __device__ unsigned long long g_trace[64 * 32];
 // Waves per SIMD the register allocation must leave room for: the eight-wave tile runs two workgroups per CU (its
 // LDS ring allows exactly two), the 128 x 128 four-wave tile three.
 constexpr int conv_dma_min_waves(int bn, int bm, int nw, bool head) {
-    return head ? 1 : nw == 8 ? 4 : (nw == 4 && bn == 128 && bm == 128) ? 3 : 1;
+    return head ? (nw == 8 ? 4 : 1) : nw == 8 ? 4 : (nw == 4 && bn == 128 && bm == 128) ? 3 : 1;
 }
 
 // KCH: 16-byte chunks per LDS row = K extent of a ring stage (4: 64-byte rows, 32 bf16 of K per step; 8: 128-byte rows,
@@ -286,7 +286,8 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     // right after the K loop, where the epilogue reads them
     YDET_STAMP(22);
     constexpr int HEAD_RP = BN + 4;   // floats per pixel row of the fp32 tile a decoding head stages in LDS
-    constexpr int CST_OFF = HEAD && BM * HEAD_RP * 4 > NSTAGE * STAGE ? BM * HEAD_RP * 4 : NSTAGE * STAGE;
+    // (a decoding head lays down the pixels of one row of waves at a time: WM of them)
+    constexpr int CST_OFF = HEAD && WM * HEAD_RP * 4 > NSTAGE * STAGE ? WM * HEAD_RP * 4 : NSTAGE * STAGE;
     float* cst = reinterpret_cast<float*>(smem + CST_OFF);
     float cst_b = 0.f, cst_ps = 0.f, cst_pb = 0.f;
     if (tid < BN) {
@@ -557,8 +558,8 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     __syncthreads();   // constants visible; also: every wave is done with the ring
     const int q = lane >> 4, px = lane & 15;
     if constexpr (HEAD) {
-        // LDS: fp32 tile [BM][HEAD_RP] at 0 (first the raw values, then their sigmoids), per-pixel records behind the
-        // per-channel constants
+        // LDS: the sigmoids of WM pixels (one row of waves) in decoded-row order at 0, per-pixel records of all BM pixels
+        // behind the per-channel constants
         float* stage = reinterpret_cast<float*>(smem);
         int* pix_row = reinterpret_cast<int*>(cst + 3 * BN);        // first z row of the pixel (anchor 0), -1: no pixel
         float* pix_gx = reinterpret_cast<float*>(pix_row + BM);
@@ -585,31 +586,13 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
         // A lane holds channels chan(i) .. + 3 of its pixels in fragment i (with bf16 raw maps the weight rows are permuted
         // so that fragments 2 s and 2 s + 1 together are the EIGHT consecutive channels of one 16-byte piece); where
         // each of those sixteen channels lands inside an anchor's rows is worked out once per lane, not per value.
-        // Pad channels (na * no .. 255) land in four spare floats behind the last anchor, whatever the pixel (their pixel
-        // stride is zero).
+        // Pad channels (na * no .. 255) land in a spare float behind the last anchor.
         float* zt = stage;
-        const int per_an = BM * h.no;                                // floats per anchor
+        const int per_an = WM * h.no;                                // floats per anchor and part
         static_assert(FN % 2 == 0, "fragments pair up");
         auto chan = [&](int i) { return wn * WN + (PERM ? 32 * (i >> 1) + 8 * q + 4 * (i & 1) : 16 * i + 4 * q); };
-        int zoff[FN][4], zmul[FN][4];       // value (i, e) of pixel pl goes to zt[zoff + pl * zmul]
-        {
-            const float rno = 1.0f / (float)h.no;
-            const int dump = h.na * per_an;        // (< BM * HEAD_RP: the tile region holds BM * 260 floats, z at most BM * 256)
-#pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const int c0 = chan(i);
-                int an = div_small(c0, h.no, rno), o = c0 - an * h.no;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    zoff[i][e] = an < h.na ? an * per_an + o : dump + e;
-                    zmul[i][e] = an < h.na ? h.no : 0;
-                    const bool wrap = o + 1 == h.no;
-                    o = wrap ? 0 : o + 1;
-                    an += wrap ? 1 : 0;
-                }
-            }
-        }
         YDET_STAMP(20);
+        // raw map out, sigmoids in place (every wave at once: this is the VALU-heavy part)
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const int pl = wm * WM + j * 16 + px;
@@ -644,82 +627,117 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) zt[zoff[i][e] + pl * zmul[i][e]] = sigmoid_fast(acc[i][j][e]);
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = sigmoid_fast(acc[i][j][e]);
         }
         if (tid < 16) anc[tid] = h.anchor[tid];
-        __syncthreads();
-        YDET_STAMP(23);
-        // (4) decode (yolov5_official/model.py:56-81).  Row maxima: one thread per (pixel, anchor) walks the classes.
-        for (int item = tid; item < BM * h.na; item += NT) {
-            const int an = item / BM, pl = item - an * BM;
-            const int row = pix_row[pl];
-            float* src = zt + an * per_an + pl * h.no;
-            const float4 s4 = make_float4(src[0], src[1], src[2], src[3]);
-            if (h.row_max && row >= 0) {
-                const float obj = src[4];
-                float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // independent chains: reads overlap
-                int c = 5;
-                for (; c + 8 <= h.no; c += 8) {
-                    float t[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = src[c + e];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) mx[e & 3] = fmaxf(mx[e & 3], t[e] * obj);
-                }
-                for (; c < h.no; ++c) mx[0] = fmaxf(mx[0], src[c] * obj);
-                h.row_max[(long long)row + (long long)an * h.hw] = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-            }
-            // the box: centre from the cell offset and the stride, size from the anchor
-            const float tx = s4.x * 2.0f, ty = s4.y * 2.0f, tw = s4.z * 2.0f, th = s4.w * 2.0f;
-            src[0] = (tx - 0.5f + pix_gx[pl]) * h.stride;
-            src[1] = (ty - 0.5f + pix_gy[pl]) * h.stride;
-            src[2] = tw * tw * anc[2 * an];
-            src[3] = th * th * anc[2 * an + 1];
-        }
-        __syncthreads();
-        YDET_STAMP(24);
-        // z: when the tile's pixels are consecutive rows of one image, each anchor's part is one run of BM*no floats in
-        // z as well, and the tile goes out as whole 16-byte pieces
+        // value (i, e) of pixel pl (of its part) goes to zt[min(zoff[i][e] + pl * no, dump)]: a pad channel's offset is
+        // `dump` itself, a spare float behind the last anchor's rows (the region holds WM * 260 floats, the rows at most
+        // WM * 256)
+        const int dump = h.na * per_an;
+        int zoff[FN][4];
         {
-            const int row0 = pix_row[0];
-            const bool run = row0 >= 0 && pix_row[BM - 1] == row0 + BM - 1;
-            const long long z0 = (long long)row0 * h.no;                       // first float of anchor 0's run
-            const int an_step = h.hw * h.no;                                   // floats between anchors (< 2^31 checked)
-            const bool vec = run && (z0 & 3) == 0 && (an_step & 3) == 0 && ((size_t)h.z & 15) == 0;
-            if (vec) {
-                const int per4 = per_an / 4, total4 = per4 * h.na;
-                const float rper4 = 1.0f / (float)per4;
-                float* zb = h.z + z0;
-                constexpr int ZU = 8;
-                for (int k0 = tid; k0 < total4; k0 += NT * ZU) {
-                    float4 v[ZU];
+            const float rno = 1.0f / (float)h.no;
 #pragma unroll
-                    for (int u = 0; u < ZU; ++u) {
-                        const int k = k0 + u * NT;
-                        if (k < total4) v[u] = *reinterpret_cast<const float4*>(zt + 4 * k);
+            for (int i = 0; i < FN; ++i) {
+                const int c0 = chan(i);
+                int an = div_small(c0, h.no, rno), o = c0 - an * h.no;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    zoff[i][e] = an < h.na ? an * per_an + o : dump;
+                    const bool wrap = o + 1 == h.no;
+                    o = wrap ? 0 : o + 1;
+                    an += wrap ? 1 : 0;
+                }
+            }
+        }
+        const int an_step = h.hw * h.no;                                   // floats of z between anchors (< 2^31 checked)
+        for (int part = 0; part < WARPS_M; ++part) {
+            // (2) the waves that hold this part's pixels lay their sigmoids down
+            if (wm == part) {
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const int pofs = (j * 16 + px) * h.no;
+#pragma unroll
+                    for (int i = 0; i < FN; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zt[min(zoff[i][e] + pofs, dump)] = acc[i][j][e];
+                }
+            }
+            __syncthreads();
+            YDET_STAMP(23);
+            // (3) decode (yolov5_official/model.py:56-81).  Row maxima: one thread per (pixel, anchor) walks the classes.
+            const int* prow = pix_row + part * WM;
+            for (int item = tid; item < WM * h.na; item += NT) {
+                const int an = item / WM, pl = item - an * WM;
+                const int row = prow[pl];
+                float* src = zt + an * per_an + pl * h.no;
+                const float4 s4 = make_float4(src[0], src[1], src[2], src[3]);
+                if (h.row_max && row >= 0) {
+                    const float obj = src[4];
+                    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // independent chains: reads overlap
+                    int c = 5;
+                    for (; c + 8 <= h.no; c += 8) {
+                        float t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t[e] = src[c + e];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) mx[e & 3] = fmaxf(mx[e & 3], t[e] * obj);
                     }
+                    for (; c < h.no; ++c) mx[0] = fmaxf(mx[0], src[c] * obj);
+                    h.row_max[(long long)row + (long long)an * h.hw] = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+                }
+                // the box: centre from the cell offset and the stride, size from the anchor
+                const float tx = s4.x * 2.0f, ty = s4.y * 2.0f, tw = s4.z * 2.0f, th = s4.w * 2.0f;
+                src[0] = (tx - 0.5f + pix_gx[part * WM + pl]) * h.stride;
+                src[1] = (ty - 0.5f + pix_gy[part * WM + pl]) * h.stride;
+                src[2] = tw * tw * anc[2 * an];
+                src[3] = th * th * anc[2 * an + 1];
+            }
+            __syncthreads();
+            YDET_STAMP(24);
+            // (4) z: when the part's pixels are consecutive rows of one image, each anchor's share is one run of WM*no
+            // floats in z as well, and it goes out as whole 16-byte pieces
+            {
+                const int row0 = prow[0];
+                const bool run = row0 >= 0 && prow[WM - 1] == row0 + WM - 1;
+                const long long z0 = (long long)row0 * h.no;                       // first float of anchor 0's run
+                const bool vec = run && (z0 & 3) == 0 && (an_step & 3) == 0 && (per_an & 3) == 0 && ((size_t)h.z & 15) == 0;
+                if (vec) {
+                    const int per4 = per_an / 4, total4 = per4 * h.na;
+                    const float rper4 = 1.0f / (float)per4;
+                    float* zb = h.z + z0;
+                    constexpr int ZU = NT >= 512 ? 4 : 8;
+                    for (int k0 = tid; k0 < total4; k0 += NT * ZU) {
+                        float4 v[ZU];
 #pragma unroll
-                    for (int u = 0; u < ZU; ++u) {
-                        const int k = k0 + u * NT;
-                        if (k < total4) {
+                        for (int u = 0; u < ZU; ++u) {
+                            const int k = k0 + u * NT;
+                            if (k < total4) v[u] = *reinterpret_cast<const float4*>(zt + 4 * k);
+                        }
+#pragma unroll
+                        for (int u = 0; u < ZU; ++u) {
+                            const int k = k0 + u * NT;
+                            if (k < total4) {
 #ifdef YDET_EXP_NO_ZST
-                            if (v[u].x != 12345.678f) continue;
+                                if (v[u].x != 12345.678f) continue;
 #endif
-                            const int an = div_small(k, per4, rper4);
-                            __builtin_nontemporal_store(f32x4{v[u].x, v[u].y, v[u].z, v[u].w},
-                                                        reinterpret_cast<f32x4*>(zb + (size_t)(unsigned)(an * an_step + (k - an * per4) * 4)));
+                                const int an = div_small(k, per4, rper4);
+                                __builtin_nontemporal_store(f32x4{v[u].x, v[u].y, v[u].z, v[u].w},
+                                                            reinterpret_cast<f32x4*>(zb + (size_t)(unsigned)(an * an_step + (k - an * per4) * 4)));
+                            }
                         }
                     }
+                } else {
+                    const float rno = 1.0f / (float)h.no;
+                    for (int an = 0; an < h.na; ++an)
+                        for (int f = tid; f < per_an; f += NT) {
+                            const int pl = div_small(f, h.no, rno), o = f - pl * h.no;
+                            const int row = prow[pl];
+                            if (row >= 0) h.z[((long long)row + (long long)an * h.hw) * h.no + o] = zt[an * per_an + f];
+                        }
                 }
-            } else {
-                const float rno = 1.0f / (float)h.no;
-                for (int an = 0; an < h.na; ++an)
-                    for (int f = tid; f < per_an; f += NT) {
-                        const int pl = div_small(f, h.no, rno), o = f - pl * h.no;
-                        const int row = pix_row[pl];
-                        if (row >= 0) h.z[((long long)row + (long long)an * h.hw) * h.no + o] = zt[an * per_an + f];
-                    }
             }
+            if (part + 1 < WARPS_M) __syncthreads();     // the next part overwrites the rows just read
         }
         YDET_STAMP(25);
         return;
@@ -1113,25 +1131,40 @@ int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
     return launch_dtype<float, float>(a, stream);
 }
 
-// 1x1 prediction convolution of one pyramid level + Detect decode in its epilogue: 256-channel x 64-pixel tiles, so a
-// workgroup owns every channel of its pixels.
-template <typename TIN, typename TRAW>
-static int launch_head(const ConvArgs& a0, const HeadArgs& h, hipStream_t stream) {
-    constexpr int BN = 256, BM = 64, BK = 64 / (int)sizeof(TIN);
+// 1x1 prediction convolution of one pyramid level + Detect decode in its epilogue: 256-channel tiles, so a workgroup
+// owns every channel of its pixels.  Two shapes: 64 pixels and four waves, or 128 pixels and eight waves (two rows of
+// waves whose pixels go through the decode one row after the other, so the LDS the decoded rows take is the same):
+// the wide one fetches the weights half as often per pixel and keeps four waves on a SIMD where the narrow one keeps
+// two; it needs enough pixels to fill the chip.
+template <typename TIN, typename TRAW, int BM, int WARPS_M, int NST>
+static int launch_head_tile(const ConvArgs& a0, const HeadArgs& h, hipStream_t stream) {
+    constexpr int BN = 256, WM = BM / WARPS_M;
     ConvArgs a = a0;
     a.tiles_n = 1;
     const long long nblk = (a.M + BM - 1) / BM;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(YDET_ERR_ARG, "head_conv_decode: grid of %lld blocks", nblk);
-    (void)BK;
-    const int ring = 3 * (BN + BM) * 64, tile = BM * (BN + 4) * 4;
+    const int ring = NST * (BN + BM) * 64, tile = WM * (BN + 4) * 4;
     const int lds = (tile > ring ? tile : ring) + 3 * BN * (int)sizeof(float) + 3 * BM * 4 + 16 * 4;
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TRAW, BN, BM, 4, 1, true>),
+        reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TRAW, BN, BM, 4, WARPS_M, true, 4, NST>),
         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "head_conv_decode: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
-    hipLaunchKernelGGL((conv_dma_kernel<TIN, TRAW, BN, BM, 4, 1, true>), dim3((unsigned)nblk), dim3(256), lds, stream, a, h);
+    hipLaunchKernelGGL((conv_dma_kernel<TIN, TRAW, BN, BM, 4, WARPS_M, true, 4, NST>), dim3((unsigned)nblk), dim3(256 * WARPS_M), lds,
+                       stream, a, h);
     YDET_CHECK_LAUNCH("conv_dma_kernel<head>");
     return YDET_OK;
+}
+
+template <typename TIN, typename TRAW>
+static int launch_head(const ConvArgs& a, const HeadArgs& h, hipStream_t stream) {
+    // YDET_HEAD_TILE=64|128 forces a shape (tuning aid)
+    static const int forced = getenv("YDET_HEAD_TILE") ? atoi(getenv("YDET_HEAD_TILE")) : 0;
+    // (measured at 64 images of 640 x 640: 196 / 67 / 38 us for the three levels with the narrow shape, 173 / 63 / 30 us
+    // with the wide one -- the 20 x 20 level, 200 wide workgroups with K = 512, gains most; below that many workgroups the
+    // narrow shape keeps more CUs busy)
+    const bool wide = forced ? forced == 128 : a.M >= 16 * 1024;
+    if (wide) return launch_head_tile<TIN, TRAW, 128, 2, 2>(a, h, stream);
+    return launch_head_tile<TIN, TRAW, 64, 1, 3>(a, h, stream);
 }
 
 int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, hipStream_t stream) {
