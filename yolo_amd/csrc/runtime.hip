@@ -137,13 +137,22 @@ static int run_ops_impl(const ydet_op* ops, int n_ops, hipStream_t s, ydet_timer
 
 // ---- independent launch lists side by side -------------------------------------------------------------------------
 // Per device: a few non-blocking side streams and the events that fork them from / join them to the caller's
-// stream.  Created on first use, kept for the life of the process (streams and events own no device memory).
+// stream.  Created on first use, kept for the life of the process (streams and events own no device memory).  One
+// pool per device: a call holds the pool's lock from its fork to its join (host-side enqueue only, nothing waits for
+// the GPU), so that two host threads on different caller streams cannot interleave their fork / wait / join on the
+// shared events; their lists still share the side streams, i.e. run one call after the other there.
 namespace {
 constexpr int kMaxLists = 4, kMaxDevices = 64;
 struct SidePool {
     bool ready = false;
     hipStream_t side[kMaxLists - 1];
     hipEvent_t fork, join[kMaxLists - 1];
+    pthread_mutex_t busy = PTHREAD_MUTEX_INITIALIZER;
+};
+struct PoolGuard {
+    pthread_mutex_t* m;
+    explicit PoolGuard(pthread_mutex_t* mm) : m(mm) { pthread_mutex_lock(m); }
+    ~PoolGuard() { pthread_mutex_unlock(m); }
 };
 SidePool g_pool[kMaxDevices];
 pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -178,6 +187,7 @@ extern "C" int ydet_run_op_lists(const ydet_op* const* lists, const int* counts,
     }
     SidePool* pool = side_pool();
     if (!pool) return ydet::fail(YDET_ERR_LAUNCH, "run_op_lists: could not create the side streams");
+    PoolGuard guard(&pool->busy);
     // fork: nothing of the side lists may start before the work already queued on the caller's stream
     if (hipEventRecord(pool->fork, main_s) != hipSuccess) return ydet::fail(YDET_ERR_LAUNCH, "run_op_lists: fork failed");
     for (int r = 1; r < n_lists; ++r)

@@ -1065,6 +1065,10 @@ class AcceleratedModule(torch.nn.Module):
         return pc
 
     def invalidate_plans(self):
+        """Drop every cached plan (folded / packed weights, launch lists, activation arenas).  Plans are rebuilt by
+        themselves when a parameter or buffer changes through an in-place torch operation or is replaced (their version
+        counters are part of the cache key); writes through `.data` (`p.data.mul_(...)`) do not move those counters:
+        call this after such an edit."""
         self._plans().clear()
 
     def _apply(self, fn, *a, **k):
@@ -1076,7 +1080,10 @@ class AcceleratedModule(torch.nn.Module):
         return super().load_state_dict(*a, **k)
 
     def train(self, mode=True):
-        self.invalidate_plans()
+        # (plans describe the eval-mode network: a change of mode drops them; `model.eval()` on a model that already is
+        # in eval mode -- val.run does that on every call -- keeps them)
+        if bool(mode) != self.training:
+            self.invalidate_plans()
         return super().train(mode)
 
 
