@@ -30,7 +30,7 @@ def label_of(name):
         nums = re.findall(r"Li(\d+)E", name) or re.findall(r"(?<![\w.])(\d+)(?=[,>])", name)
         bn, bm = nums[0], nums[1]
         if kind == "dma":
-            if re.search(r"Li1ELb1E|, true>", name):      # HEAD = true: the prediction conv with the decode epilogue
+            if re.search(r"Li\d+ELb1E|, true(, \d+, \d+)?>", name):      # HEAD = true: the prediction conv with the decode epilogue
                 return "conv_head_decode"
             return f"conv_dma<{bn}x{bm},{dts}>"
         one = "Lb1E" in name or re.search(r"true>", name)
