@@ -1028,6 +1028,9 @@ class PlanCache:
             self.signature = sig
         # a plan owns its activation arena: forward passes issued on different streams may overlap on the GPU and must
         # not share one, so the stream is part of the key (callers that pipeline batches over two streams get two plans)
+        # the planner switches (fusions on / off, dtype of the raw head maps, batch split) shape the launch list: a
+        # plan built under other settings is not reused
+        key = (key, _fuse_upsample, _fuse_followers, _fuse_focus_pair, _head_raw_compute, _batch_split)
         if torch.cuda.is_available() and torch.cuda.is_initialized():
             key = (key, torch.cuda.current_stream().cuda_stream)
         p = self.plans.get(key)
