@@ -371,12 +371,16 @@ def other_configs(dev, args):
     """The other benchmark configurations, each forward + decode + per-class NMS of every image on one GPU:
     C1 YOLOv3-tiny 416 batch 1 (with the CPU restatement of the same path on the host cores, all threads and one thread),
     C2 YOLOv2-D19 416 batch 32, C3 YOLOv3-SPP 608 batch 64, C4 YOLOv4 608 batch 64 (its single-GPU shard)."""
+    from yolo_amd import engine
     from yolo_amd.synthetic import images
     out = {}
     for name, tag, size, batch, steps in (("C1", "v3tiny", 416, 1, 50), ("C2", "v2d19", 416, 32, 10), ("C3", "v3spp", 608, 64, 5),
                                           ("C4", "v4", 608, 64, 5)):
         net = build_family_a(tag, size).to(dev)
         x = images(batch, size, seed=1, kind="randn").to(dev)
+        # a single image leaves the deepest layers a handful of tiles each: their K is split over workgroups (opt-in: the
+        # order of the fp32 sums then depends on the launch shape)
+        engine.set_split_k(batch == 1)
         with torch.no_grad():
             for _ in range(2):
                 net.detect_batch(x)
@@ -386,8 +390,9 @@ def other_configs(dev, args):
                 net.detect_batch(x)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
+        engine.set_split_k(False)
         out[name] = {"workload": f"{tag} {size}x{size} batch {batch}, forward + decode + per-class NMS", "images_per_s": round(batch / dt, 1),
-                     "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": args.compute}
+                     "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": args.compute, "split_k": batch == 1}
         if name == "C1" and not args.no_cpu:
             out[name]["cpu_baseline"] = cpu_baseline_c1(net, x.cpu())
         del net, x

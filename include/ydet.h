@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 13
+#define YDET_ABI_VERSION 14
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -125,8 +125,19 @@ typedef struct {
      * stride + 1.  Either one sends the launch to a direct (non-MFMA) kernel; y2, x_up, pw_w and cout_store are then
      * not available.  0 means 1 (cin_group: Cin / groups). */
     int32_t groups, dilation, cin_group;
+    /* Optional K split, for launches of a few tiles and a long K (single images, the deepest layers: one workgroup per
+     * tile walks all of K alone while most of the chip idles): with a workspace of at least
+     * ydet_conv_splitk_workspace_bytes(d) bytes (256-byte aligned) the filter taps of a k x k convolution, or channel
+     * ranges of a 1x1 one, are spread over several workgroups whose fp32 partial sums a second kernel adds up before
+     * bias / activation / residual.  The result differs from the unsplit launch by the order of the fp32 additions
+     * only -- and therefore, unlike everything else here, may differ between batch sizes.  NULL = never split.  bf16
+     * inputs, Cin a multiple of 64; excludes pw_w and x_up. */
+    void* splitk_ws;
+    int64_t splitk_ws_bytes;
 } ydet_conv_desc;
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
+/* Bytes of splitk_ws with which ydet_conv2d_nhwc would split this convolution's K; 0: it would not. */
+size_t ydet_conv_splitk_workspace_bytes(const ydet_conv_desc* d);
 
 /* Focus + the first convolution, straight from the NCHW image: yolov5_official/modules.py:285-293 (the slicing
  * torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1) followed by Conv) when it is

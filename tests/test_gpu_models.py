@@ -316,6 +316,28 @@ def test_family_a_heads_golden(golden, compute, tag, size):
         assert rel_err(h.cpu().numpy(), g["head_" + name]) < tol, name
 
 
+@pytest.mark.parametrize("tag,size", [("v3tiny", 416), ("v2d19", 416), ("v3spp", 128), ("v4", 128)])
+def test_family_a_heads_golden_with_split_k(golden, tag, size):
+    """The same single-image head maps with the K of the few-tile / long-K layers split over workgroups
+    (engine.set_split_k): some launches really are split, the bf16 bar against the reference's maps holds, and the maps
+    equal the unsplit ones up to the order of fp32 additions."""
+    g = golden(f"g6_{tag}_{size}")
+    engine.set_compute_dtype("bf16")
+    net = build_fa(tag, size).to(DEV)
+    x = images(1, size, seed=int(g["x_seed"]), kind="randn").to(DEV)
+    plain = [h.float().cpu() for h in net.head_maps(x)]
+    engine.set_split_k(True)
+    try:
+        heads = [h.float().cpu() for h in net.head_maps(x)]
+        plans = list(net._plans().plans.values())
+        assert any(p.splitk_ws and p.splitk_ws[0] is not None for p in plans), "no launch was split"
+    finally:
+        engine.set_split_k(False)
+    for h, h0, name in zip(heads, plain, FA_SPECS[tag][3]):
+        assert rel_err(h.numpy(), g["head_" + name]) < 5e-2, name
+        assert rel_err(h.numpy(), h0.numpy()) < 2e-2, name
+
+
 @pytest.mark.parametrize("tag,size", FA_CASES)
 def test_family_a_detections(golden, tag, size):
     """forward() contract: numpy (bboxes [K,4] f32, scores [K] f32, cls [K] i64) of image 0 in box-index order.

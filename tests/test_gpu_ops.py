@@ -536,6 +536,43 @@ def test_grouped_modules_lower():
         assert rel_err(out["y"].float().cpu(), ref) < 1e-3, name
 
 
+# ---- K split over workgroups (opt-in) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("geom", [(1, 256, 512, 3, 1, 13, 13, False), (1, 1024, 256, 1, 1, 13, 13, False), (2, 512, 256, 3, 2, 26, 22, False),
+                                  (1, 256, 256, 3, 1, 20, 20, True), (3, 1024, 512, 1, 1, 7, 9, True), (1, 128, 192, 5, 1, 11, 11, False)])
+def test_conv_split_k(geom):
+    """Few tiles and a long K: with engine.set_split_k the taps (k x k) or channel ranges (1x1) go to different workgroups
+    and a second kernel adds the partial sums before bias / activation / residual.  Against the unsplit launch (same
+    values up to the order of the fp32 additions: bf16 outputs differ in few places, by one ulp) and against torch."""
+    N, cin, cout, k, s, H, W, res = geom
+    gen = _gen(31, f"splitk{geom}")
+    x = torch.randn(N, cin, H, W, generator=gen).bfloat16().float()
+    conv = nn.Conv2d(cin, cout, k, s, k // 2).requires_grad_(False)
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (cin * k * k)) ** 0.5)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    r = torch.randn(N, cout, Ho, Wo, generator=gen).bfloat16().float() if res else None
+
+    def build(gr, ins):
+        kw = dict(res=ins[1], res_mode=_ffi.RES_AFTER_ACT) if res else {}
+        gr.to_nchw(gr.conv(ins[0], conv, act=_ffi.ACT_LEAKY, slope=0.1, **kw), "y")
+
+    outs = {}
+    for split in (True, False):
+        engine.set_split_k(split)
+        try:
+            g = engine.Graph(DEV, "bf16")
+            build(g, [g.input_nchw(*t.shape) for t in ([x, r] if res else [x])])
+            plan = g.finalize()
+            conv_op = [op for op in plan.ops if op.kind == _ffi.OP_CONV][0]
+            assert bool(conv_op.conv.splitk_ws) == split, "the launch was expected to qualify for a K split"
+            outs[split] = plan.run(*[t.to(DEV) for t in ([x, r] if res else [x])])["y"].float().cpu()
+        finally:
+            engine.set_split_k(False)
+    ref = F.leaky_relu(conv(x), 0.1) + (r if res else 0)
+    assert rel_err(outs[True].numpy(), ref.numpy()) < 2e-2
+    assert rel_err(outs[True].numpy(), outs[False].numpy()) < 1e-2
+    assert (outs[True] != outs[False]).float().mean() < 0.05
+
+
 def test_conv_argument_validation():
     lib = _ffi.lib()
     d = _ffi.ConvDesc()

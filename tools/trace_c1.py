@@ -15,6 +15,7 @@ from yolo_amd import engine  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 engine.set_compute_dtype(sys.argv[2] if len(sys.argv) > 2 else "bf16")
+engine.set_split_k(len(sys.argv) > 3 and sys.argv[3] == "splitk")
 dev = torch.device("cuda:0")
 net = bench.build_family_a("v3tiny", 416).to(dev)
 x = images(1, 416, seed=1, kind="randn").to(dev)

@@ -16,7 +16,7 @@ RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
  OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK, OP_C3_TAIL, OP_RGB_CONV, OP_FOCUS_PAIR) = range(15)
 MAX_ANCHORS = 8
-ABI_VERSION = 13   # YDET_ABI_VERSION of include/ydet.h these structs were written against
+ABI_VERSION = 14   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("x_up", C.c_void_p), ("x_up_ld", C.c_int32), ("x_up_coff", C.c_int32), ("x_up_C", C.c_int32),
         ("pw_w", C.c_void_p), ("pw_bias", C.c_void_p), ("pw_cout", C.c_int32), ("pw_kp", C.c_int32),
         ("groups", C.c_int32), ("dilation", C.c_int32), ("cin_group", C.c_int32),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -94,6 +95,7 @@ SYMBOLS = {
     "ydet_last_error": (C.c_char_p, []),
     "ydet_abi_version": (C.c_int, []),
     "ydet_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ydet_conv_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "ydet_focus_conv3x3_nchw": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_focus_conv_pair_nchw": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_rgb_conv3x3_nchw": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),

@@ -275,7 +275,12 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     const int wn = wave % WARPS_N, wm = wave / WARPS_N;
     YDET_STAMP(0);
 
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    int split = 0;
+    if (!HEAD && a.splits > 1) {          // (consecutive ids = the tiles of one split: they share its slab of the weights)
+        split = (int)(bid / (unsigned)a.tiles_per_split);
+        bid -= (unsigned)split * (unsigned)a.tiles_per_split;
+    }
     const int tile_n = bid % a.tiles_n;
     const long long tile_m = bid / a.tiles_n;
     const int n0 = tile_n * BN;
@@ -394,10 +399,27 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     int tap = 0, c0 = 0, kh = 0, kw = 0;
     long long tapoff = 0;  // byte offset of (kh, kw, c0) relative to a row pointer
     int ktile = 0;         // next tile to issue
+    int nk = a.kp / BK;    // K-steps of this workgroup
+    long long wbase = 0;   // byte offset of its first K value in a weight row
+    if (!HEAD && a.splits > 1) {
+        if (a.split_taps > 0) {
+            tap = split * a.split_taps;
+            const int ntap = min(a.split_taps, a.KH * a.KW - tap);
+            kh = tap / a.KW;
+            kw = tap - kh * a.KW;
+            nk = ntap * a.Cin / BK;
+            wbase = (long long)tap * a.Cin * (long long)sizeof(TIN);
+        } else {
+            c0 = split * a.split_cin;
+            nk = a.split_cin / BK;
+            wbase = (long long)c0 * (long long)sizeof(TIN);
+        }
+        tapoff = ((long long)(kh * a.W + kw) * a.x_ld + c0) * (long long)sizeof(TIN);
+    }
 
     auto issue = [&](int stage) {
         char* dst = smem + stage * STAGE + wave * 1024;
-        const long long woff = (long long)ktile * BK * (long long)sizeof(TIN);
+        const long long woff = wbase + (long long)ktile * BK * (long long)sizeof(TIN);
 #ifdef YDET_EXP_SKIP_W
         if (ktile == 0)
 #endif
@@ -455,7 +477,6 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
         }
     }
 
-    const int nk = a.kp / BK;
     YDET_STAMP(1);
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
@@ -745,6 +766,7 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     // The values a lane holds for a pixel are whole 16-byte pieces of the output row (see PERM above): they leave
     // straight from registers, no pass through LDS.  Piece p of a lane: CP channels from chan(p) on, out of fragments
     // 2 p and 2 p + 1 (bf16 outputs) or fragment p (fp32 outputs).
+    char* ybase = a.y + (long long)split * a.split_stride;      // (a K split writes partial sums: one slab per split)
     constexpr int CP = PERM ? 8 : 4;                  // channels per piece
     constexpr int NP = PERM ? FN / 2 : FN;            // pieces per lane and pixel
     static_assert(!PERM || FN % 2 == 0, "bf16 pieces pair up fragments");
@@ -798,7 +820,7 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
                 if (!okm || co >= a.cout_store) continue;
                 // channels from y_split on belong to the second destination
                 char* dst = co >= a.y_split ? a.y2 + ((size_t)m * a.y2_ld + a.y2_coff + (co - a.y_split)) * sizeof(TOUT)
-                                            : a.y + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT);
+                                            : ybase + ((size_t)m * a.y_ld + a.y_coff + co) * sizeof(TOUT);
                 if constexpr (PERM) {
                     bf16x8 t;
 #pragma unroll
@@ -819,7 +841,7 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
         for (int j = 0; j < FM; ++j) {
             const long long m = m0 + wm * WM + j * 16 + px;
             if (m >= a.M) continue;
-            char* yrow = a.y + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
+            char* yrow = ybase + ((size_t)m * a.y_ld + a.y_coff) * sizeof(TOUT);
             const char* rrow = a.res ? a.res + ((size_t)m * a.res_ld + a.res_coff) * sizeof(TIN) : nullptr;
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
@@ -898,7 +920,8 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const long long tiles_m = (a.M + BM - 1) / BM;
-    const long long nblk = tiles_m * a.tiles_n;
+    a.tiles_per_split = (int)(tiles_m * a.tiles_n);
+    const long long nblk = tiles_m * a.tiles_n * (a.splits > 1 ? a.splits : 1);
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(YDET_ERR_ARG, "conv: grid of %lld blocks", nblk);
     constexpr int BK = KCH * 16 / (int)sizeof(TIN);
     if constexpr (KCH != 4) {
@@ -980,6 +1003,7 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
             // keep the default choice)
             if (got == 4 && kch == 8 && a.Cin % 64 == 0 && a.KH * a.KW <= 32 && a.Cout > 64) {
                 if (bn == 128 && bm == 128 && nst == 2) return launch_tile<TIN, TOUT, 128, 128, 2, 2, 8, 2>(a, stream);
+                if (bn == 128 && bm == 128 && nst == 4) return launch_tile<TIN, TOUT, 128, 128, 2, 2, 8, 4>(a, stream);
                 if (bn == 128 && bm == 64 && nst == 3) return launch_tile<TIN, TOUT, 128, 64, 2, 2, 8, 3>(a, stream);
             }
         }
@@ -1007,8 +1031,14 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
         const long long tiles = (a.M + 127) / 128 * ((a.Cout + 127) / 128);
         const int K = a.KH * a.KW * a.Cin;
         static const bool k8_on = !(getenv("YDET_CONV_K8") && atoi(getenv("YDET_CONV_K8")) == 0);
-        if (k8_on && a.Cin % 64 == 0 && a.KH * a.KW <= 32 && K >= 256 && (tiles <= 512 || (tiles <= 1024 && K >= 2048)))
+        if (k8_on && a.Cin % 64 == 0 && a.KH * a.KW <= 32 && K >= 256 && (tiles <= 512 || (tiles <= 1024 && K >= 2048))) {
+            // At most one tile per CU and a long K (single images, the deepest layers): the launch is as long as one
+            // workgroup's walk over K, which waits for HBM at every step -- a four-stage ring (128 KB of LDS, one
+            // workgroup per CU is all there is anyway) keeps three steps in flight instead of one.  The order of the
+            // sums does not change.
+            if (tiles <= 256 && K >= 1024) return launch_tile<TIN, TOUT, 128, 128, 2, 2, 8, 4>(a, stream);
             return launch_tile<TIN, TOUT, 128, 128, 2, 2, 8, 2>(a, stream);
+        }
     }
     if (sizeof(TOUT) == 2 && wide_tile_pays(a.M, a.Cout, a.KH * a.KW * a.Cin, a.Cin % (64 / (int)sizeof(TIN)) == 0 && a.KH * a.KW <= 32))
         return launch_tile<TIN, TOUT, 128, 256, 2, 4>(a, stream);
@@ -1103,6 +1133,7 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
         a.vec_store = (d->pw_cout % 4 == 0 && d->y_ld % 4 == 0 && d->y_coff % 4 == 0) ? 1 : 0;
     }
     a.groups = groups; a.dilation = dil; a.cin_group = cin_group;
+    a.splits = 0; a.tiles_per_split = 0; a.split_taps = 0; a.split_cin = 0; a.split_stride = 0;
     a.x_up = nullptr; a.up_ld = 0; a.up_coff = 0; a.up_C = 0;
     if (d->x_up) {
         YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H % 2 == 0 && d->W % 2 == 0,
@@ -1121,10 +1152,123 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     return YDET_OK;
 }
 
+// ---- K split over workgroups ------------------------------------------------------------------------------------------
+namespace {
+struct SplitPlan {
+    int splits, split_taps, split_cin, ldw;
+    long long tiles;
+    size_t bytes;
+};
+
+// Whether (and how) a launch is split: at most 64 tiles of 128 x 128 (a quarter of the CUs), K >= 1024, bf16 inputs with
+// Cin a multiple of 64, nothing fused in that needs the whole K in one workgroup.  Taps of a k x k convolution in equal
+// groups, channels of a 1x1 one in equal ranges of a multiple of 64, towards one workgroup per CU.
+bool plan_splitk(const ydet_conv_desc* d, const ConvArgs& a, SplitPlan& p) {
+    if (d->in_dtype != YDET_BF16 || a.groups > 1 || a.dilation > 1 || a.pw_w || a.x_up || a.Cin % 64 != 0 || a.KH * a.KW > 32 ||
+        a.Cout <= 64)
+        return false;
+    p.tiles = (a.M + 127) / 128 * ((a.Cout + 127) / 128);
+    const long long K = (long long)a.KH * a.KW * a.Cin;
+    if (p.tiles > 64 || K < 1024) return false;
+    const int want = (int)(256 / p.tiles) < 16 ? (int)(256 / p.tiles) : 16;
+    const int taps = a.KH * a.KW;
+    p.split_taps = p.split_cin = 0;
+    if (taps > 1) {
+        p.split_taps = (taps + want - 1) / want;
+        p.splits = (taps + p.split_taps - 1) / p.split_taps;
+    } else {
+        int s = want;
+        while (s > 1 && a.Cin % (s * 64) != 0) --s;
+        p.splits = s;
+        p.split_cin = a.Cin / s;
+    }
+    if (p.splits < 2) return false;
+    p.ldw = (a.Cout + 3) / 4 * 4;
+    if (p.ldw > d->cout_pad) return false;
+    p.bytes = (size_t)p.splits * (size_t)a.M * (size_t)p.ldw * sizeof(float);
+    return true;
+}
+
+struct ReduceArgs {
+    const float* ws;
+    int splits, ldw;
+    long long slab;     // floats per split
+};
+
+// Sum of the splits' partial sums, then what the convolution's own epilogue does: bias, activation, residual (either
+// order), the optional second stage; four channels per thread, stored as one piece where the slice allows.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, const ReduceArgs r) {
+    const int per = r.ldw / 4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long m = idx / per;
+    const int c = (int)(idx - m * per) * 4;
+    if (m >= a.M) return;
+    const float* src = r.ws + m * r.ldw + c;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < r.splits; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (long long)s * r.slab);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.res) {
+        const __bf16* rr = reinterpret_cast<const __bf16*>(a.res) + (size_t)m * a.res_ld + a.res_coff + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < a.Cout) res[e] = (float)rr[e];
+    }
+    finish4<-1>(v, res, a.bias ? a.bias + c : nullptr, a.post_scale ? a.post_scale + c : nullptr,
+                a.post_scale ? a.post_shift + c : nullptr, a);
+    const bool second = c >= a.y_split;
+    char* row = second ? a.y2 + ((size_t)m * a.y2_ld + a.y2_coff + (c - a.y_split)) * sizeof(TOUT)
+                       : a.y + ((size_t)m * a.y_ld + a.y_coff + c) * sizeof(TOUT);
+    const bool whole = c + 4 <= a.cout_store && (second || c + 4 <= a.y_split) && a.vec_store && ((uintptr_t)row & (4 * sizeof(TOUT) - 1)) == 0;
+    if (whole) {
+        store4<TOUT>(row, v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < a.cout_store && !(c < a.y_split && c + e >= a.y_split)) reinterpret_cast<TOUT*>(row)[e] = from_f32<TOUT>(v[e]);
+    }
+}
+
+int launch_splitk(const ydet_conv_desc* d, const ConvArgs& a, const SplitPlan& p, hipStream_t stream) {
+    YDET_CHECK_ARG(((uintptr_t)d->splitk_ws & 255) == 0, "conv: splitk_ws must be 256-byte aligned");
+    ConvArgs part = a;
+    part.bias = nullptr; part.res = nullptr; part.res_mode = YDET_RES_NONE; part.act = YDET_ACT_NONE; part.slope = 1.0f;
+    part.post_scale = nullptr; part.post_shift = nullptr; part.y2 = nullptr; part.y_split = 0x7fffffff;
+    part.y = (char*)d->splitk_ws; part.y_ld = p.ldw; part.y_coff = 0; part.cout_store = p.ldw; part.vec_store = 1;
+    part.splits = p.splits; part.split_taps = p.split_taps; part.split_cin = p.split_cin;
+    part.split_stride = (long long)a.M * p.ldw * (long long)sizeof(float);
+    const int rc = launch_tile<__bf16, float, 128, 128, 2, 2, 8, 4>(part, stream);
+    if (rc != YDET_OK) return rc;
+    ReduceArgs r;
+    r.ws = (const float*)d->splitk_ws; r.splits = p.splits; r.ldw = p.ldw; r.slab = a.M * p.ldw;
+    const long long items = a.M * (p.ldw / 4);
+    const unsigned blocks = (unsigned)((items + 255) / 256);
+    if (d->out_dtype == YDET_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream, a, r);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, a, r);
+    YDET_CHECK_LAUNCH("splitk_reduce_kernel");
+    return YDET_OK;
+}
+}  // namespace
+
+extern "C" size_t ydet_conv_splitk_workspace_bytes(const ydet_conv_desc* d) {
+    clear_error();
+    ConvArgs a;
+    SplitPlan p;
+    if (!d || fill_conv_args(d, a) != YDET_OK) return 0;
+    return plan_splitk(d, a, p) ? (p.bytes + 255) / 256 * 256 : 0;
+}
+
 int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream) {
     ConvArgs a;
     const int rc = fill_conv_args(d, a);
     if (rc != YDET_OK) return rc;
+    if (d->splitk_ws) {
+        SplitPlan p;
+        if (plan_splitk(d, a, p) && (size_t)d->splitk_ws_bytes >= p.bytes) return launch_splitk(d, a, p, stream);
+    }
     if (d->in_dtype == YDET_BF16)
         return d->out_dtype == YDET_BF16 ? launch_dtype<__bf16, __bf16>(a, stream)
                                          : launch_dtype<__bf16, float>(a, stream);

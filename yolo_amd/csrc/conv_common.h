@@ -38,6 +38,11 @@ struct ConvArgs {
     int groups, dilation, cin_group;   // direct kernel only (groups > 1 or dilation > 1)
     const char* x_up; // pointwise convs only: input channels [0, up_C) are read from this map of half the size at
     int up_ld, up_coff, up_C;   // (h/2, w/2) -- a nearest-neighbour 2x upsample that is never materialised; 0: none
+    // K split over workgroups (launches of a few tiles and a long K): workgroup id = split * tiles_per_split + tile;
+    // split s walks filter taps [s * split_taps, ...) (split_taps > 0) or input channels [s * split_cin, ...) of a 1x1
+    // convolution, and writes its fp32 partial sums at y + s * split_stride.  splits <= 1: the whole K, as ever.
+    int splits, tiles_per_split, split_taps, split_cin;
+    long long split_stride;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -610,6 +610,18 @@ class Plan:
             for i, (kind, a) in enumerate(g.ops):
                 self._fill(ops[i], i, kind, a, arena, record=(r == 0))
             self.op_lists.append(ops)
+        # K split of the few-tile / long-K convolutions (set_split_k): one workspace per launch list, sized for the largest
+        # taker (the ops of a list run one after the other)
+        self.splitk_ws = []
+        if _split_k and g.device != "cpu" and torch.device(g.device).type == "cuda":
+            lib = _ffi.lib()
+            for ops in self.op_lists:
+                need = [int(lib.ydet_conv_splitk_workspace_bytes(C.byref(op.conv))) if op.kind == _ffi.OP_CONV else 0 for op in ops]
+                ws = torch.empty(max(need), dtype=torch.uint8, device=g.device) if max(need, default=0) > 0 else None
+                self.splitk_ws.append(ws)
+                for op, nb in zip(ops, need):
+                    if nb > 0:
+                        op.conv.splitk_ws, op.conv.splitk_ws_bytes = ws.data_ptr(), ws.numel()
         self.ops = self.op_lists[0]
         self._lists = (C.POINTER(_ffi.Op) * replicas)(*[C.cast(o, C.POINTER(_ffi.Op)) for o in self.op_lists])
         self._counts = (C.c_int * replicas)(*([n] * replicas))
@@ -839,6 +851,7 @@ _fuse_upsample = True
 _fuse_followers = True
 _fuse_focus_pair = True
 _head_raw_compute = True
+_split_k = False
 
 
 def set_focus_pair_fusion(flag):
@@ -846,6 +859,15 @@ def set_focus_pair_fusion(flag):
     launches with the 32-channel half-size map written and read back (ablation / comparison)."""
     global _fuse_focus_pair
     _fuse_focus_pair = bool(flag)
+
+
+def set_split_k(flag):
+    """Whether plans spread the K of few-tile / long-K convolutions (single images, the deepest layers) over several
+    workgroups (default off).  On: several times faster for such launches; the order of the fp32 additions then depends
+    on the launch shape, so an image's result may differ in the last bits between batch sizes -- off, every image of a
+    batch equals its own single-image run bit for bit."""
+    global _split_k
+    _split_k = bool(flag)
 
 
 def set_head_raw_dtype(mode):
@@ -1030,7 +1052,7 @@ class PlanCache:
         # not share one, so the stream is part of the key (callers that pipeline batches over two streams get two plans)
         # the planner switches (fusions on / off, dtype of the raw head maps, batch split) shape the launch list: a
         # plan built under other settings is not reused
-        key = (key, _fuse_upsample, _fuse_followers, _fuse_focus_pair, _head_raw_compute, _batch_split)
+        key = (key, _fuse_upsample, _fuse_followers, _fuse_focus_pair, _head_raw_compute, _batch_split, _split_k)
         if torch.cuda.is_available() and torch.cuda.is_initialized():
             key = (key, torch.cuda.current_stream().cuda_stream)
         p = self.plans.get(key)
