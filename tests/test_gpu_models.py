@@ -338,6 +338,23 @@ def test_family_a_heads_golden_with_split_k(golden, tag, size):
         assert rel_err(h.numpy(), h0.numpy()) < 2e-2, name
 
 
+def test_graph_replay_equals_eager():
+    """detect_batch of YOLOv3-tiny at batch 1 (forward + decode + per-class NMS: every launch of the step) captured once
+    and replayed for other images gives bit for bit what the eager calls give."""
+    engine.set_compute_dtype("bf16")
+    net = build_fa("v3tiny", 416).to(DEV)
+    xs = [images(1, 416, seed=70 + i, kind="randn").to(DEV) for i in range(3)]
+    with torch.no_grad():
+        eager = [[t.clone() for t in net.detect_batch(x)] for x in xs]
+        replay = engine.GraphReplay(net.detect_batch)
+        for rep in range(2):
+            for x, ref in zip(xs, eager):
+                out = replay(x)
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(out, ref)), rep
+    assert len(replay.cache) == 1 and any(bool(e[3].any()) for e in [eager[0]])
+
+
 @pytest.mark.parametrize("tag,size", FA_CASES)
 def test_family_a_detections(golden, tag, size):
     """forward() contract: numpy (bboxes [K,4] f32, scores [K] f32, cls [K] i64) of image 0 in box-index order.

@@ -1061,6 +1061,48 @@ class PlanCache:
         return p
 
 
+class GraphReplay:
+    """fn(*device tensors) -> device tensors, replayed from a captured HIP graph: for callers whose host thread cannot
+    keep up with enqueuing a step's launches (a Python loop doing other work between steps).  Measured on MI355X with
+    YOLOv3-tiny at batch 1 (forty launches, 0.24 ms of host time per eager step): 0.298 ms per replayed step against
+    0.290 ms eager with an otherwise idle host -- the step is bound by the dependency gaps between its short kernels on
+    the GPU, which a graph does not close, so nothing here uses it by default.
+
+    The first call per input signature (shapes, dtypes, device) runs fn eagerly on a side stream -- plans are built, the
+    kernels' one-time attribute calls made -- and then once more under capture on that same stream (plans are cached per
+    stream).  Later calls copy their inputs into the captured input buffers and launch the graph on the current stream.
+    The tensors returned are the graph's own output buffers: valid until the next call with the same signature.  fn must
+    not synchronise with the host or read device values (the launch lists, the decode and the padded NMS entry points
+    of this package do not)."""
+
+    def __init__(self, fn, warmup=2):
+        self.fn, self.warmup, self.cache = fn, warmup, {}
+
+    def __call__(self, *xs):
+        key = tuple((tuple(x.shape), x.dtype, x.device) for x in xs)
+        ent = self.cache.get(key)
+        if ent is None:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=xs[0].device)
+            static_in = [torch.empty_like(x) for x in xs]
+            for b, x in zip(static_in, xs):
+                b.copy_(x)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self.fn(*static_in)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                out = self.fn(*static_in)
+            ent = self.cache[key] = (graph, static_in, out)
+        graph, static_in, out = ent
+        for b, x in zip(static_in, xs):
+            b.copy_(x, non_blocking=True)
+        graph.replay()
+        return out
+
+
 _compute_override = None
 
 
