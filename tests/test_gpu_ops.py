@@ -573,6 +573,36 @@ def test_conv_split_k(geom):
     assert (outs[True] != outs[False]).float().mean() < 0.05
 
 
+def test_conv_split_k_two_destinations():
+    """A split launch whose output channels go to two buffers (the sibling pair of a C3 written separately): the
+    reduction kernel sends every 4-channel group to the right one."""
+    gen = _gen(32, "splitk_y2")
+    x = torch.randn(1, 1024, 13, 13, generator=gen).bfloat16().float()
+    c1, c2 = nn.Conv2d(1024, 64, 1).requires_grad_(False), nn.Conv2d(1024, 96, 1).requires_grad_(False)
+    for c in (c1, c2):
+        c.weight.copy_(torch.randn(c.weight.shape, generator=gen) * (2.0 / 1024) ** 0.5)
+
+    def build(gr, ins):
+        _, (y, y2) = gr.conv_siblings(ins[0], [(c1, None), (c2, None)], act=_ffi.ACT_SILU, separate=True)
+        gr.to_nchw(y, "y")
+        gr.to_nchw(y2, "y2")
+
+    outs = {}
+    for split in (True, False):
+        engine.set_split_k(split)
+        try:
+            g = engine.Graph(DEV, "bf16")
+            build(g, [g.input_nchw(*x.shape)])
+            plan = g.finalize()
+            assert bool([op for op in plan.ops if op.kind == _ffi.OP_CONV][0].conv.splitk_ws) == split
+            outs[split] = {k: v.float().cpu() for k, v in plan.run(x.to(DEV)).items()}
+        finally:
+            engine.set_split_k(False)
+    for k, c in (("y", c1), ("y2", c2)):
+        assert rel_err(outs[True][k].numpy(), F.silu(c(x)).numpy()) < 2e-2, k
+        assert rel_err(outs[True][k].numpy(), outs[False][k].numpy()) < 1e-2, k
+
+
 def test_conv_argument_validation():
     lib = _ffi.lib()
     d = _ffi.ConvDesc()
