@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 14
+#define YDET_ABI_VERSION 15
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -364,8 +364,14 @@ int ydet_nms_cluster_diou(const float* pred, int N, int nboxes, int no, float co
  * (equal scores: higher box index first, i.e. a stable ascending sort reversed) with
  * w,h = max(1e-28, .) and survivors ovr <= nms_thresh (NaN suppresses).
  * out_keep [N, n] uint8 (1 = kept, original box order), out_cls [N, n] int32 (argmax class),
- * out_score [N, n] fp32 (best score). */
+ * out_score [N, n] fp32 (best score).
+ * Workspace: ..._workspace_bytes holds, beside the index lists, room for the suppression bit matrices of long class
+ * segments (1024 boxes and more: every pair tested by the whole chip at once, then one workgroup per segment walks the
+ * rows; the upper triangle of n x n bits per image); anything from ..._workspace_bytes_min up is accepted, and segments
+ * whose matrix finds no room are walked round by round instead (same result, slower when thousands of boxes of one
+ * class survive). */
 size_t ydet_nms_perclass_workspace_bytes(int N, int n, int nc);
+size_t ydet_nms_perclass_workspace_bytes_min(int N, int n, int nc);
 int ydet_nms_perclass(const float* boxes, const float* scores, int N, int n, int nc,
                       float conf_thresh, float nms_thresh, uint8_t* out_keep, int32_t* out_cls,
                       float* out_score, void* workspace, size_t workspace_bytes, void* stream);

@@ -253,6 +253,66 @@ def test_nms_perclass_single_class_large():
     assert np.nonzero(keep[0].cpu().numpy())[0].tolist() == ref
 
 
+def _skewed_classes(seed, N, n, nc, heavy):
+    """Boxes of which most fall in the first len(heavy) classes (fractions `heavy`), with repeated boxes and tied scores."""
+    g = _gen(seed, "skewed-classes")
+    c = torch.rand(N, n, 2, generator=g)
+    wh = torch.rand(N, n, 2, generator=g) * 0.12 + 0.01
+    bb = torch.cat([c - wh / 2, c + wh / 2], 2).clamp(0, 1)
+    bb[:, 100:200] = bb[:, 300:400]                       # identical boxes
+    sc = torch.rand(N, n, nc, generator=g) * 0.3
+    u = torch.rand(N, n, generator=g)
+    top = torch.rand(N, n, generator=g) * 0.5 + 0.4
+    top = (top * 64).round() / 64                         # many equal scores
+    lo = 0.0
+    for k, f in enumerate(heavy):
+        m = (u >= lo) & (u < lo + f)
+        sc[..., k][m] = top[m]
+        lo += f
+    return bb, sc
+
+
+@pytest.mark.parametrize("workspace", [None, "min", "one"])
+def test_nms_perclass_long_segments(workspace):
+    """Class segments of thousands of boxes: the bit-matrix path (full workspace), the round-by-round walk (minimal
+    workspace) and a workspace with room for the first long segment of an image only -- all equal to the oracle."""
+    N, n, nc = 3, 6000, 5
+    bb, sc = _skewed_classes(11, N, n, nc, (0.5, 0.3))
+    lib = _ffi.lib()
+    ws = workspace
+    best_h, cls_h = sc.max(2)
+    counts_h = np.stack([np.bincount(cls_h[i][best_h[i] >= 0.05].numpy(), minlength=nc) for i in range(N)])
+    words = lambda cnt: 64 * (((cnt + 63) // 64) * ((cnt + 63) // 64 + 1) // 2)      # upper triangle, 64-row strips
+    assert counts_h[:, 0].min() > 2500 and counts_h[:, 1].min() > 1300        # both sides of the 1024-box rule are hit
+    assert 0 < counts_h[:, 2:].max() < 1024
+    if workspace == "one":      # room for the matrix of the first class of every image and not for the second one's
+        room = max(words(int(c)) for c in counts_h[:, 0])
+        assert all(room - words(int(c0)) < words(int(c1)) for c0, c1 in counts_h[:, :2])
+        ws = lib.ydet_nms_perclass_workspace_bytes_min(N, n, nc) + N * 8 * room
+    keep, cls, best = ops.nms_perclass(bb.to(DEV), sc.to(DEV), 0.05, 0.45, workspace_bytes=ws)
+    for i in range(N):
+        rb, rs, rc = O.postprocess(bb[i].numpy(), sc[i].numpy(), 0.05, nc, 0.45)
+        k = keep[i].bool().cpu().numpy()
+        assert k.sum() == len(rb)
+        np.testing.assert_array_equal(bb[i].numpy()[k], rb)
+        np.testing.assert_array_equal(best[i].cpu().numpy()[k], rs)
+        np.testing.assert_array_equal(cls[i].cpu().numpy()[k], rc)
+
+
+def test_nms_perclass_segment_not_multiple_of_64_all_kept():
+    """Disjoint boxes (nothing suppressed: the longest walk) in one class, lengths around the block size."""
+    for n in (1024, 1025, 1087, 1088, 2049):
+        ix = torch.arange(n, dtype=torch.float32)
+        bb = torch.stack([ix * 2, torch.zeros(n), ix * 2 + 1, torch.ones(n)], 1)
+        sc = torch.rand(n, 1, generator=_gen(n, "all-kept")) + 0.1
+        keep, _, _ = ops.nms_perclass(bb.to(DEV)[None], sc.to(DEV)[None], 0.0, 0.5)
+        assert int(keep.sum()) == n
+        # and every box identical: only the best one survives
+        keep, _, _ = ops.nms_perclass(bb[:1].repeat(n, 1).to(DEV)[None], sc.to(DEV)[None], 0.0, 0.5)
+        k = np.nonzero(keep[0].cpu().numpy())[0].tolist()
+        assert k == sorted(O.nms_numpy(bb[:1].repeat(n, 1).numpy(), sc[:, 0].numpy(), 0.5))
+
+
 def test_box_iou(golden):
     g = golden("g7_v5_metrics")
     iou = ops.box_iou(torch.from_numpy(g["box1"]).to(DEV), torch.from_numpy(g["box2"]).to(DEV))

@@ -16,7 +16,7 @@ RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
  OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK, OP_C3_TAIL, OP_RGB_CONV, OP_FOCUS_PAIR) = range(15)
 MAX_ANCHORS = 8
-ABI_VERSION = 14   # YDET_ABI_VERSION of include/ydet.h these structs were written against
+ABI_VERSION = 15   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -131,6 +131,7 @@ SYMBOLS = {
     "ydet_nms_cluster_diou": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ydet_nms_perclass_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ydet_nms_perclass_workspace_bytes_min": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ydet_nms_perclass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ydet_box_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -613,6 +613,12 @@ struct FAArgs {
     unsigned* sorted;     // [N][n]  same, sorted by descending score inside each class
     float4* sbox;         // [N][n]  the boxes in that order (one gather, then contiguous reads)
     unsigned* alive;      // [N][n]  second index list of the greedy kernel (the first one reuses seg)
+    // long class segments: suppression bit matrix built by the whole chip, then walked by one workgroup
+    unsigned* unit_prefix;   // [N * nc + 1]  running count of 64-row strips over the segments that got a matrix
+    u64* mat_off;            // [N * nc]      word offset of the segment's matrix inside its image's region, ~0: none
+    unsigned* queue;         // next strip to hand out
+    u64* mat;                // [N][mat_words]
+    u64 mat_words;           // per image; 0: no matrix region in the workspace
 };
 
 // argmax class (first maximum), threshold, per-class population count.  The 256 boxes of a workgroup are one
@@ -723,6 +729,192 @@ __global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
 
 constexpr int kFaMaxWords = 2048;  // up to 131072 boxes per class segment
 
+// Class segments of at least this many boxes take the matrix path when their matrix fits the image's region.
+constexpr int kFaMatrixMin = 1024;
+constexpr u64 kFaNoMatrix = ~0ull;
+
+// The matrix of a segment of cnt boxes (W = ceil(cnt / 64) blocks of 64): strips of 64 rows, strip rb holding the
+// tiles of column blocks rb .. W - 1 one after the other, a tile = 64 words, one per COLUMN: word j has bit i set when
+// box 64 rb + i suppresses box 64 cb + j (i before j on the diagonal tile).  Only the upper triangle exists.
+__device__ __forceinline__ u64 fa_strip_words(int W, int rb) { return 64ull * ((u64)rb * (u64)W - (u64)rb * (u64)(rb - 1) / 2ull); }
+static inline u64 fa_matrix_words(int cnt) {
+    const u64 W = ((u64)cnt + 63) >> 6;
+    return 64ull * (W * (W + 1) / 2ull);
+}
+
+__device__ __forceinline__ float vmax_raw(float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float vmin_raw(float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float vfloor28_raw(float x) { float r; asm("v_max_f32 %0, 0x10fd87b6, %1" : "=v"(r) : "v"(x)); return r; }   // max(1e-28f, x)
+
+// v_cmp_class_f32 as a lane mask (every lane of the wave must be active)
+__device__ __forceinline__ u64 class_mask(float x, int classes) {
+    u64 m;
+    asm("v_cmp_class_f32 %0, %1, %2" : "=s"(m) : "v"(x), "s"(classes));
+    return m;
+}
+
+// One 64 x 64 tile: lane j holds column box bj and returns its word, bit i = suppresses<true>(row box i, bj).
+// The verdict is !(fl(inter / uni) <= thr).  Rounding is monotone and thr is a float, so inter <= thr uni (in the reals)
+// means survive and inter >= nextup(thr) uni means suppressed; both are decided without the division wherever inter is
+// outside thr (1 -+ 2^-21) uni, products rounded (2^-24 each, with the bound on the product keeping them out of the
+// subnormals).  If any column of a group of eight rows is inside that band, holds a NaN, or thr uni is not a positive
+// normal number (uni = +0 and uni < 0 aside), the wave evaluates the reference expression for the group: the result is the
+// division's, bit for bit.
+// inter and uni are computed exactly as suppresses<true> does (the bare v_max / v_min differ from fmaxf / fminf only for
+// signalling NaNs, which end up undecided).  Rows are read from LDS at wave-uniform addresses.  GENERIC: the diagonal
+// tile (row i tests the columns beyond i) or a strip of fewer than 64 rows.
+// A lane collects its column's verdicts one bit per row: bits = 2 bits + verdict is one add-with-carry with the verdict
+// mask as the carry-in (rows 0..31 and 32..63 in a register each, first row in the top bit).  All mask logic is scalar
+// and kept short: the scalar unit is shared by the four SIMDs of a CU.
+template <bool GENERIC>
+__device__ __forceinline__ u64 tile_column_word(const float4* rbox, const float* rarea, const float4& bj, float aj, float thr,
+                                                float thr_lo, float thr_hi, u64 cols, bool diag, int nrow) {
+    unsigned half[2];
+    const bool thr_nonneg = thr >= 0.f;
+#pragma unroll 1
+    for (int hf = 0; hf < 2; ++hf) {
+        unsigned bits = 0u;
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            const int i0 = hf * 32 + g * 8;
+            u64 words[8];
+            u64 undecided = thr_nonneg ? 0ull : ~0ull;      // (a negative or NaN threshold: the reference expression throughout)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 bi = rbox[i0 + k];
+                const float ai = rarea[i0 + k];
+                const float xx1 = vmax_raw(bi.x, bj.x), yy1 = vmax_raw(bi.y, bj.y);
+                const float xx2 = vmin_raw(bi.z, bj.z), yy2 = vmin_raw(bi.w, bj.w);
+                const float w = vfloor28_raw(xx2 - xx1), h = vfloor28_raw(yy2 - yy1);
+                const float inter = w * h;
+                const float uni = ai + aj - inter;
+                const float p_lo = thr_lo * uni, p_hi = thr_hi * uni;
+                const u64 m_hi = __builtin_amdgcn_ballot_w64(inter >= p_hi);
+                const u64 m_lo = __builtin_amdgcn_ballot_w64(inter <= p_lo);
+                const u64 m_ok = __builtin_amdgcn_ballot_w64(p_lo >= 1e-30f);
+                // Boxes without area (clipped away at the image border) are common and leave uni at or below zero.
+                // uni = +0: inter / uni is +inf or NaN, suppressed either way -- and inter >= p_hi = 0 says so already.
+                // uni negative and finite (two such boxes overlapping along a line: inter is a tiny positive number; a
+                // finite uni means a finite inter): the quotient is negative or -0, which is <= thr for any thr >= 0 --
+                // survives.
+                const u64 m_zero = class_mask(uni, 0x40);         // +0
+                const u64 m_neg = class_mask(uni, 0x18);          // -normal | -subnormal
+                words[k] = m_hi & ~m_neg;
+                undecided |= ~(((m_hi | m_lo) & m_ok) | m_zero | m_neg);
+            }
+            if (__builtin_expect((undecided & cols) != 0ull, 0)) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    words[k] = __builtin_amdgcn_ballot_w64(suppresses<true>(rbox[i0 + k], rarea[i0 + k], bj, aj, thr));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k;
+                const u64 live = !GENERIC ? cols : i >= nrow ? 0ull : diag ? cols & ~((2ull << i) - 1ull) : cols;
+                const u64 word = words[k] & live;
+                asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(word) : "vcc");
+            }
+        }
+        half[hf] = __builtin_bitreverse32(bits);
+    }
+    return ((u64)half[1] << 32) | (u64)half[0];
+}
+
+// One workgroup: which segments get a matrix (in class order while the image's region has room), where, and the
+// running strip count the matrix kernel's queue is searched with.
+__global__ __launch_bounds__(1024) void fa_plan_kernel(const FAArgs a) {
+    __shared__ unsigned s_scan[1024];
+    __shared__ unsigned s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_carry = 0; *a.queue = 0; }
+    __syncthreads();
+    for (int base = 0; base < a.N; base += 1024) {
+        const int img = base + tid;
+        unsigned units = 0;
+        if (img < a.N) {
+            u64 used = 0;
+            for (int c = 0; c < a.nc; ++c) {
+                const unsigned cnt = a.count[(size_t)img * a.nc + c];
+                const u64 W = ((u64)cnt + 63) >> 6, words = 64ull * (W * (W + 1) / 2ull);
+                const bool sel = cnt >= (unsigned)kFaMatrixMin && used + words <= a.mat_words;
+                a.mat_off[(size_t)img * a.nc + c] = sel ? used : kFaNoMatrix;
+                if (sel) { used += words; units += (unsigned)W; }
+            }
+        }
+        s_scan[tid] = units;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const unsigned v = tid >= d ? s_scan[tid - d] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        unsigned run = s_scan[tid] - units + s_carry;
+        if (img < a.N)
+            for (int c = 0; c < a.nc; ++c) {
+                const size_t s = (size_t)img * a.nc + c;
+                a.unit_prefix[s] = run;
+                if (a.mat_off[s] != kFaNoMatrix) run += (a.count[s] + 63u) >> 6;
+            }
+        __syncthreads();
+        if (tid == 1023) s_carry += s_scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) a.unit_prefix[(size_t)a.N * a.nc] = s_carry;
+}
+
+// Strips are handed out through a counter; a workgroup's four waves share a strip's 64 row boxes (LDS, read at
+// wave-uniform addresses) and take its tiles in turn: lane j holds column box j and collects the verdicts of the 64 rows
+// against it.  Every pair gets the verdict of the expression the round-by-round walk below evaluates, operands in the
+// same order.
+__global__ __launch_bounds__(256) void fa_matrix_kernel(const FAArgs a) {
+    __shared__ float4 s_rbox[64];
+    __shared__ float s_rarea[64];
+    __shared__ unsigned s_unit;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = a.N * a.nc;
+    const unsigned total = a.unit_prefix[S];
+    const float thr_lo = a.thr * 0.99999952316284f, thr_hi = a.thr * 1.00000047683716f;   // thr (1 -+ 2^-21)
+    while (true) {
+        if (tid == 0) s_unit = atomicAdd(a.queue, 1u);
+        __syncthreads();
+        const unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)s_unit);
+        if (u >= total) break;           // (the same u for the whole workgroup)
+        int lo = 0, hi = S;              // unit_prefix[lo] <= u < unit_prefix[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.unit_prefix[mid] <= u) lo = mid; else hi = mid;
+        }
+        const int seg = lo, rb = (int)(u - a.unit_prefix[seg]);
+        const int img = seg / a.nc, c = seg - img * a.nc;
+        const unsigned* count = a.count + (size_t)img * a.nc;
+        const int cnt = (int)count[c];
+        const float4* sbox = a.sbox + (size_t)img * a.n + fa_class_offset(count, c);
+        const int W = (cnt + 63) >> 6, r0 = rb * 64;
+        u64* strip = a.mat + (size_t)img * a.mat_words + a.mat_off[seg] + fa_strip_words(W, rb);
+        if (tid < 64) {
+            const float4 b = r0 + tid < cnt ? sbox[r0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s_rbox[tid] = b;
+            s_rarea[tid] = box_area(b);
+        }
+        __syncthreads();
+        const int nrow = min(64, cnt - r0);
+        for (int cb = rb + wv; cb < W; cb += 4) {
+            const int cj = cb * 64 + lane;
+            const bool okj = cj < cnt;
+            const float4 bj = okj ? sbox[cj] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float aj = box_area(bj);
+            const u64 cols = __ballot(okj);
+            const bool diag = cb == rb;
+            const u64 word = diag || nrow < 64
+                                 ? tile_column_word<true>(s_rbox, s_rarea, bj, aj, a.thr, thr_lo, thr_hi, cols, diag, nrow)
+                                 : tile_column_word<false>(s_rbox, s_rarea, bj, aj, a.thr, thr_lo, thr_hi, cols, false, 64);
+            strip[(size_t)(cb - rb) * 64 + lane] = word;
+        }
+        __syncthreads();                 // the row boxes and s_unit are rewritten next
+    }
+}
+
 constexpr int kFaNmsThreads = 1024;   // four threads per later box when a chunk's survivors are applied (long class segments)
 
 // One workgroup per (class, image) segment, boxes in descending score order.  The greedy rule of utils/utils.py:15-42
@@ -746,6 +938,75 @@ __global__ __launch_bounds__(kFaNmsThreads) void fa_nms_kernel(const FAArgs a) {
     unsigned* cur = a.seg + (size_t)img * a.n + off;      // (the class lists are no longer needed once ranked)
     unsigned* nxt = a.alive + (size_t)img * a.n + off;
     uint8_t* keep = a.keep + (size_t)img * a.n;
+    if (a.mat_words && a.mat_off[(size_t)img * a.nc + c] != kFaNoMatrix) {
+        // The segment's suppression matrix exists: walk its strips.  removed[w] collects the columns of block w that a kept
+        // box of an earlier strip suppresses.
+        __shared__ u64 s_removed[kFaMaxWords];
+        const int W = (cnt + 63) >> 6;
+        for (int w = tid; w < W; w += kFaNmsThreads) s_removed[w] = 0ull;
+        __syncthreads();
+        const u64* mat = a.mat + (size_t)img * a.mat_words + a.mat_off[(size_t)img * a.nc + c];
+        // A strip's words are requested while the strip before it is walked (they do not depend on what it keeps): the
+        // diagonal tile by the first wave, the first kPre passes over the later blocks by every thread.
+        constexpr int kPre = 5;                 // 5 passes x 1024 columns: segments of up to 81 blocks entirely
+        u64 next_diag = tid < 64 ? mat[tid] : 0ull;
+        u64 next_later[kPre];
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const int col = tid + q * kFaNmsThreads;
+            next_later[q] = col < (W - 1) * 64 ? mat[64 + col] : 0ull;
+        }
+        for (int rb = 0; rb < W; ++rb) {
+            const u64* strip = mat + fa_strip_words(W, rb);
+            const int later = (W - rb - 1) * 64;
+            const u64 colw = next_diag;
+            u64 cur_later[kPre];
+#pragma unroll
+            for (int q = 0; q < kPre; ++q) cur_later[q] = next_later[q];
+            if (rb + 1 < W) {
+                const u64* nstrip = mat + fa_strip_words(W, rb + 1);
+                if (tid < 64) next_diag = nstrip[tid];
+#pragma unroll
+                for (int q = 0; q < kPre; ++q) {
+                    const int col = tid + q * kFaNmsThreads;
+                    next_later[q] = col < later - 64 ? nstrip[64 + col] : 0ull;
+                }
+            }
+            if (tid < 64) {
+                // The diagonal tile.  A position depends on the positions before it only, so the greedy set K is the one
+                // fixed point of K = open & ~{j : column j has a row of K}, and iterating from any start settles at least
+                // one more leading position per pass (64 passes at most; a handful when suppression chains are short).
+                const int nrow = min(64, cnt - rb * 64);
+                const u64 valid = nrow == 64 ? ~0ull : ((1ull << nrow) - 1ull);
+                const u64 open = valid & ~s_removed[rb];
+                u64 kp = open;
+                for (int pass = 0; pass < 64; ++pass) {
+                    const u64 nk = open & ~__ballot((colw & kp) != 0ull);
+                    if (nk == kp) break;
+                    kp = nk;
+                }
+                if ((kp >> tid) & 1ull) keep[sorted[rb * 64 + tid]] = 1;
+                if (tid == 0) sh.kept_word = kp;
+            }
+            __syncthreads();
+            const u64 kp = sh.kept_word;
+            // the later blocks: a thread per column, a wave per block and pass (so each word of `removed` has one writer)
+#pragma unroll
+            for (int q = 0; q < kPre; ++q) {
+                const int col = tid + q * kFaNmsThreads;
+                if (col - lane < later) {                  // (the same for the whole wave)
+                    const u64 hit = __ballot((cur_later[q] & kp) != 0ull);
+                    if (lane == 0 && hit) s_removed[rb + 1 + (col >> 6)] |= hit;
+                }
+            }
+            for (int col = tid + kPre * kFaNmsThreads; col < later; col += kFaNmsThreads) {
+                const u64 hit = __ballot((strip[64 + col] & kp) != 0ull);
+                if (lane == 0 && hit) s_removed[rb + 1 + (col >> 6)] |= hit;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int s = tid; s < cnt; s += kFaNmsThreads) cur[s] = (unsigned)s;
     __syncthreads();
     int L = cnt;
@@ -834,17 +1095,34 @@ __global__ __launch_bounds__(kFaNmsThreads) void fa_nms_kernel(const FAArgs a) {
     }
 }
 
-size_t fa_ws_layout(int N, int n, int nc, size_t* o_count, size_t* o_cursor, size_t* o_seg, size_t* o_sorted) {
+struct FaLayout {
+    size_t count, cursor, seg, sorted, sbox, alive, prefix, matoff, queue;   // byte offsets
+    size_t base_bytes;   // everything the walk needs
+    size_t mat;          // offset of the matrix region
+    u64 mat_words;       // words per image of a full-size region
+    size_t bytes;        // with the full-size region
+};
+
+FaLayout fa_ws_layout(int N, int n, int nc) {
+    FaLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += (bytes + 255) & ~(size_t)255; return r; };
-    const size_t c0 = take((size_t)N * nc * sizeof(unsigned));
-    const size_t c1 = take((size_t)N * nc * sizeof(unsigned));
-    const size_t sg = take((size_t)N * n * sizeof(unsigned));
-    const size_t so = take((size_t)N * n * sizeof(unsigned));
-    take((size_t)N * n * sizeof(float4));      // sorted boxes: right behind `sorted`
-    take((size_t)N * n * sizeof(unsigned));    // second index list
-    if (o_count) { *o_count = c0; *o_cursor = c1; *o_seg = sg; *o_sorted = so; }
-    return off;
+    L.count = take((size_t)N * nc * sizeof(unsigned));
+    L.cursor = take((size_t)N * nc * sizeof(unsigned));
+    L.seg = take((size_t)N * n * sizeof(unsigned));
+    L.sorted = take((size_t)N * n * sizeof(unsigned));
+    L.sbox = take((size_t)N * n * sizeof(float4));      // sorted boxes
+    L.alive = take((size_t)N * n * sizeof(unsigned));   // second index list
+    L.prefix = take(((size_t)N * nc + 1) * sizeof(unsigned));
+    L.matoff = take((size_t)N * nc * sizeof(u64));
+    L.queue = take(sizeof(unsigned));
+    L.base_bytes = off;
+    // matrix region per image: what ONE class holding every box needs (the upper triangle of n x n bits; any split of the
+    // boxes over classes needs less), so with a full-size workspace no segment ever goes without
+    L.mat_words = n >= kFaMatrixMin ? fa_matrix_words(n) : 0;
+    L.mat = take((size_t)N * L.mat_words * sizeof(u64));
+    L.bytes = off;
+    return L;
 }
 
 // box_iou: yolov5_official/utils.py:601-611 (clamp(0), no epsilon)
@@ -1145,7 +1423,12 @@ extern "C" int ydet_nms_v5_static(const float* pred, int N, int nboxes, int no, 
 
 extern "C" size_t ydet_nms_perclass_workspace_bytes(int N, int n, int nc) {
     if (N <= 0 || n <= 0 || nc <= 0) return 0;
-    return fa_ws_layout(N, n, nc, nullptr, nullptr, nullptr, nullptr);
+    return fa_ws_layout(N, n, nc).bytes;
+}
+
+extern "C" size_t ydet_nms_perclass_workspace_bytes_min(int N, int n, int nc) {
+    if (N <= 0 || n <= 0 || nc <= 0) return 0;
+    return fa_ws_layout(N, n, nc).base_bytes;
 }
 
 extern "C" int ydet_nms_perclass(const float* boxes, const float* scores, int N, int n, int nc, float conf_thresh,
@@ -1158,29 +1441,36 @@ extern "C" int ydet_nms_perclass(const float* boxes, const float* scores, int N,
     YDET_CHECK_ARG(N <= 65535 && nc <= 65535, "nms_perclass: N or nc exceeds 65535");
     YDET_CHECK_ARG(((uintptr_t)boxes & 15) == 0, "nms_perclass: boxes must be 16-byte aligned");
     YDET_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "nms_perclass: workspace must be 256-byte aligned");
-    size_t oc, ou, og, os;
-    const size_t need = fa_ws_layout(N, n, nc, &oc, &ou, &og, &os);
-    if (workspace_bytes < need)
-        return fail(YDET_ERR_WORKSPACE, "nms_perclass: workspace %zu < %zu bytes", workspace_bytes, need);
+    const FaLayout L = fa_ws_layout(N, n, nc);
+    if (workspace_bytes < L.base_bytes)
+        return fail(YDET_ERR_WORKSPACE, "nms_perclass: workspace %zu < %zu bytes", workspace_bytes, L.base_bytes);
     hipStream_t s = as_stream(stream);
     char* ws = (char*)workspace;
     FAArgs a;
     a.boxes = boxes; a.scores = scores; a.N = N; a.n = n; a.nc = nc; a.conf = conf_thresh; a.thr = nms_thresh;
     a.keep = out_keep; a.cls = out_cls; a.best = out_score;
-    a.count = (unsigned*)(ws + oc); a.cursor = (unsigned*)(ws + ou);
-    a.seg = (unsigned*)(ws + og); a.sorted = (unsigned*)(ws + os);
-    {
-        const size_t idx = ((size_t)N * n * sizeof(unsigned) + 255) & ~(size_t)255, bx = ((size_t)N * n * sizeof(float4) + 255) & ~(size_t)255;
-        a.sbox = (float4*)(ws + os + idx);
-        a.alive = (unsigned*)(ws + os + idx + bx);
-    }
-    if (hipMemsetAsync(ws + oc, 0, og - oc, s) != hipSuccess)
+    a.count = (unsigned*)(ws + L.count); a.cursor = (unsigned*)(ws + L.cursor);
+    a.seg = (unsigned*)(ws + L.seg); a.sorted = (unsigned*)(ws + L.sorted);
+    a.sbox = (float4*)(ws + L.sbox); a.alive = (unsigned*)(ws + L.alive);
+    a.unit_prefix = (unsigned*)(ws + L.prefix); a.mat_off = (u64*)(ws + L.matoff); a.queue = (unsigned*)(ws + L.queue);
+    a.mat = (u64*)(ws + L.mat);
+    // a workspace of ydet_nms_perclass_workspace_bytes holds the full matrix region; a smaller one (at least the base
+    // part) gets what is left per image, down to none: segments without a matrix are walked round by round
+    a.mat_words = 0;
+    if (L.mat_words && workspace_bytes > L.mat)
+        a.mat_words = std::min<u64>(L.mat_words, (u64)((workspace_bytes - L.mat) / sizeof(u64) / (size_t)N));
+    if (a.mat_words < fa_matrix_words(kFaMatrixMin)) a.mat_words = 0;
+    if (hipMemsetAsync(ws + L.count, 0, L.seg - L.count, s) != hipSuccess)
         return fail(YDET_ERR_LAUNCH, "nms_perclass: hipMemsetAsync failed");
     const long long total = (long long)N * n;
     const unsigned g1 = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(fa_score_kernel, dim3(g1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(fa_scatter_kernel, dim3(g1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(fa_rank_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nc, (unsigned)N), dim3(256), 0, s, a);
+    if (a.mat_words) {
+        hipLaunchKernelGGL(fa_plan_kernel, dim3(1), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(fa_matrix_kernel, dim3(2048), dim3(256), 0, s, a);
+    }
     hipLaunchKernelGGL(fa_nms_kernel, dim3((unsigned)nc, (unsigned)N), dim3(kFaNmsThreads), 0, s, a);
     YDET_CHECK_LAUNCH("nms_perclass kernels");
     return YDET_OK;

@@ -189,9 +189,11 @@ def nms_cluster_diou(pred, conf_thres=0.1, iou_thres=0.6, max_box=1500, classes=
     return rows, count
 
 
-def nms_perclass(boxes, scores, conf_thresh, nms_thresh):
+def nms_perclass(boxes, scores, conf_thresh, nms_thresh, workspace_bytes=None):
     """boxes [N, n, 4], scores [N, n, nc] fp32 CUDA.
-    Returns (keep [N, n] uint8, cls [N, n] int32, best [N, n] fp32): utils/utils.py:101-133."""
+    Returns (keep [N, n] uint8, cls [N, n] int32, best [N, n] fp32): utils/utils.py:101-133.
+    workspace_bytes: None = the full size (bit matrices for long class segments); "min" or a byte count in between
+    leave some or all segments to the round-by-round walk (same result)."""
     _need_cuda(boxes, scores)
     lib = _ffi.lib()
     boxes = boxes.float().contiguous()
@@ -204,6 +206,9 @@ def nms_perclass(boxes, scores, conf_thresh, nms_thresh):
     if N == 0 or n == 0:
         return keep, cls, best
     ws_bytes = lib.ydet_nms_perclass_workspace_bytes(N, n, nc)
+    if workspace_bytes is not None:
+        ws_min = lib.ydet_nms_perclass_workspace_bytes_min(N, n, nc)
+        ws_bytes = ws_min if workspace_bytes == "min" else max(ws_min, min(ws_bytes, int(workspace_bytes)))
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
         _ffi.check(lib.ydet_nms_perclass(boxes.data_ptr(), scores.data_ptr(), N, n, nc, float(conf_thresh),
