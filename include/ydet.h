@@ -366,7 +366,7 @@ int ydet_nms_cluster_diou(const float* pred, int N, int nboxes, int no, float co
  * out_keep [N, n] uint8 (1 = kept, original box order), out_cls [N, n] int32 (argmax class),
  * out_score [N, n] fp32 (best score).
  * Workspace: ..._workspace_bytes holds, beside the index lists, room for the suppression bit matrices of long class
- * segments (1024 boxes and more: every pair tested by the whole chip at once, then one workgroup per segment walks the
+ * segments (256 boxes and more: every pair tested by the whole chip at once, then one workgroup per segment walks the
  * rows; the upper triangle of n x n bits per image); anything from ..._workspace_bytes_min up is accepted, and segments
  * whose matrix finds no room are walked round by round instead (same result, slower when thousands of boxes of one
  * class survive). */

@@ -276,15 +276,15 @@ def _skewed_classes(seed, N, n, nc, heavy):
 def test_nms_perclass_long_segments(workspace):
     """Class segments of thousands of boxes: the bit-matrix path (full workspace), the round-by-round walk (minimal
     workspace) and a workspace with room for the first long segment of an image only -- all equal to the oracle."""
-    N, n, nc = 3, 6000, 5
+    N, n, nc = 3, 6000, 12
     bb, sc = _skewed_classes(11, N, n, nc, (0.5, 0.3))
     lib = _ffi.lib()
     ws = workspace
     best_h, cls_h = sc.max(2)
     counts_h = np.stack([np.bincount(cls_h[i][best_h[i] >= 0.05].numpy(), minlength=nc) for i in range(N)])
     words = lambda cnt: 64 * (((cnt + 63) // 64) * ((cnt + 63) // 64 + 1) // 2)      # upper triangle, 64-row strips
-    assert counts_h[:, 0].min() > 2500 and counts_h[:, 1].min() > 1300        # both sides of the 1024-box rule are hit
-    assert 0 < counts_h[:, 2:].max() < 1024
+    assert counts_h[:, 0].min() > 2500 and counts_h[:, 1].min() > 1300        # both sides of the 256-box rule are hit
+    assert 0 < counts_h[:, 2:].max() < 256
     if workspace == "one":      # room for the matrix of the first class of every image and not for the second one's
         room = max(words(int(c)) for c in counts_h[:, 0])
         assert all(room - words(int(c0)) < words(int(c1)) for c0, c1 in counts_h[:, :2])
@@ -301,7 +301,7 @@ def test_nms_perclass_long_segments(workspace):
 
 def test_nms_perclass_segment_not_multiple_of_64_all_kept():
     """Disjoint boxes (nothing suppressed: the longest walk) in one class, lengths around the block size."""
-    for n in (1024, 1025, 1087, 1088, 2049):
+    for n in (255, 256, 257, 319, 320, 1025, 2049):
         ix = torch.arange(n, dtype=torch.float32)
         bb = torch.stack([ix * 2, torch.zeros(n), ix * 2 + 1, torch.ones(n)], 1)
         sc = torch.rand(n, 1, generator=_gen(n, "all-kept")) + 0.1

@@ -729,8 +729,10 @@ __global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
 
 constexpr int kFaMaxWords = 2048;  // up to 131072 boxes per class segment
 
-// Class segments of at least this many boxes take the matrix path when their matrix fits the image's region.
-constexpr int kFaMatrixMin = 1024;
+// Class segments of at least this many boxes take the matrix path when their matrix fits the image's region (shorter
+// ones are a few rounds of the walk; from about a thousand boxes on, mostly kept, the walk takes hundreds of
+// microseconds: every round's survivors test up to 64 kept boxes one after the other).
+constexpr int kFaMatrixMin = 256;
 constexpr u64 kFaNoMatrix = ~0ull;
 
 // The matrix of a segment of cnt boxes (W = ceil(cnt / 64) blocks of 64): strips of 64 rows, strip rb holding the
@@ -946,62 +948,75 @@ __global__ __launch_bounds__(kFaNmsThreads) void fa_nms_kernel(const FAArgs a) {
         for (int w = tid; w < W; w += kFaNmsThreads) s_removed[w] = 0ull;
         __syncthreads();
         const u64* mat = a.mat + (size_t)img * a.mat_words + a.mat_off[(size_t)img * a.nc + c];
-        // A strip's words are requested while the strip before it is walked (they do not depend on what it keeps): the
-        // diagonal tile by the first wave, the first kPre passes over the later blocks by every thread.
-        constexpr int kPre = 5;                 // 5 passes x 1024 columns: segments of up to 81 blocks entirely
-        u64 next_diag = tid < 64 ? mat[tid] : 0ull;
-        u64 next_later[kPre];
-#pragma unroll
-        for (int q = 0; q < kPre; ++q) {
-            const int col = tid + q * kFaNmsThreads;
-            next_later[q] = col < (W - 1) * 64 ? mat[64 + col] : 0ull;
-        }
-        for (int rb = 0; rb < W; ++rb) {
+        // One barrier per strip: while waves 1..15 apply what strip rb keeps to the blocks beyond rb + 1, the first wave
+        // applies it to block rb + 1 itself and goes on to resolve that block's diagonal tile -- the only serial chain.
+        // A strip's words are requested one strip ahead (they do not depend on what is kept).
+        __shared__ u64 s_kept[2];
+        constexpr int kOthers = kFaNmsThreads - 64;       // threads of waves 1..15: one column each per pass
+        constexpr int kPre = 6;                           // passes held in registers (segments of up to 92 blocks entirely)
+        // The diagonal tile of a strip, by the first wave.  A position depends on the positions before it only, so the
+        // greedy set K is the one fixed point of K = open & ~{j : column j has a row of K}, and iterating from any start
+        // settles at least one more leading position per pass (64 passes at most).
+        auto resolve_diag = [&](int rb, u64 colw, u64 removed) {
+            const int nrow = min(64, cnt - rb * 64);
+            const u64 valid = nrow == 64 ? ~0ull : ((1ull << nrow) - 1ull);
+            const u64 open = valid & ~removed;
+            u64 kp = open;
+            for (int pass = 0; pass < 64; ++pass) {
+                const u64 nk = open & ~__ballot((colw & kp) != 0ull);
+                if (nk == kp) break;
+                kp = nk;
+            }
+            if ((kp >> lane) & 1ull) keep[sorted[rb * 64 + lane]] = 1;
+            if (lane == 0) s_kept[rb & 1] = kp;
+        };
+        // first wave: diagonal word of strip rb + 1 and the word of block rb + 1 in strip rb; the others: columns of the
+        // blocks beyond rb + 1 in strip rb
+        u64 w0_diag = 0ull, w0_next = 0ull, pre[kPre];
+        auto request = [&](int rb) {          // what iteration rb consumes
             const u64* strip = mat + fa_strip_words(W, rb);
-            const int later = (W - rb - 1) * 64;
-            const u64 colw = next_diag;
-            u64 cur_later[kPre];
-#pragma unroll
-            for (int q = 0; q < kPre; ++q) cur_later[q] = next_later[q];
-            if (rb + 1 < W) {
-                const u64* nstrip = mat + fa_strip_words(W, rb + 1);
-                if (tid < 64) next_diag = nstrip[tid];
+            if (wv == 0) {
+                if (rb + 1 < W) {
+                    w0_next = strip[64 + lane];
+                    w0_diag = mat[fa_strip_words(W, rb + 1) + lane];
+                }
+            } else {
+                const int later = (W - rb - 2) * 64;      // columns beyond block rb + 1
 #pragma unroll
                 for (int q = 0; q < kPre; ++q) {
-                    const int col = tid + q * kFaNmsThreads;
-                    next_later[q] = col < later - 64 ? nstrip[64 + col] : 0ull;
+                    const int col = tid - 64 + q * kOthers;
+                    pre[q] = col < later ? strip[128 + col] : 0ull;
                 }
             }
-            if (tid < 64) {
-                // The diagonal tile.  A position depends on the positions before it only, so the greedy set K is the one
-                // fixed point of K = open & ~{j : column j has a row of K}, and iterating from any start settles at least
-                // one more leading position per pass (64 passes at most; a handful when suppression chains are short).
-                const int nrow = min(64, cnt - rb * 64);
-                const u64 valid = nrow == 64 ? ~0ull : ((1ull << nrow) - 1ull);
-                const u64 open = valid & ~s_removed[rb];
-                u64 kp = open;
-                for (int pass = 0; pass < 64; ++pass) {
-                    const u64 nk = open & ~__ballot((colw & kp) != 0ull);
-                    if (nk == kp) break;
-                    kp = nk;
-                }
-                if ((kp >> tid) & 1ull) keep[sorted[rb * 64 + tid]] = 1;
-                if (tid == 0) sh.kept_word = kp;
-            }
-            __syncthreads();
-            const u64 kp = sh.kept_word;
-            // the later blocks: a thread per column, a wave per block and pass (so each word of `removed` has one writer)
+        };
+        if (wv == 0) resolve_diag(0, mat[lane], 0ull);
+        request(0);
+        __syncthreads();
+        for (int rb = 0; rb + 1 < W; ++rb) {
+            const u64* strip = mat + fa_strip_words(W, rb);
+            const u64 kp = s_kept[rb & 1];
+            const u64 c_diag = w0_diag, c_next = w0_next;
+            u64 cur[kPre];
 #pragma unroll
-            for (int q = 0; q < kPre; ++q) {
-                const int col = tid + q * kFaNmsThreads;
-                if (col - lane < later) {                  // (the same for the whole wave)
-                    const u64 hit = __ballot((cur_later[q] & kp) != 0ull);
-                    if (lane == 0 && hit) s_removed[rb + 1 + (col >> 6)] |= hit;
+            for (int q = 0; q < kPre; ++q) cur[q] = pre[q];
+            request(rb + 1);
+            if (wv == 0) {
+                const u64 removed = s_removed[rb + 1] | __ballot((c_next & kp) != 0ull);
+                resolve_diag(rb + 1, c_diag, removed);
+            } else {
+                const int later = (W - rb - 2) * 64;
+#pragma unroll
+                for (int q = 0; q < kPre; ++q) {
+                    const int col = tid - 64 + q * kOthers;
+                    if (col - lane < later) {              // (the same for the whole wave)
+                        const u64 hit = __ballot((cur[q] & kp) != 0ull);
+                        if (lane == 0 && hit) s_removed[rb + 2 + (col >> 6)] |= hit;
+                    }
                 }
-            }
-            for (int col = tid + kPre * kFaNmsThreads; col < later; col += kFaNmsThreads) {
-                const u64 hit = __ballot((strip[64 + col] & kp) != 0ull);
-                if (lane == 0 && hit) s_removed[rb + 1 + (col >> 6)] |= hit;
+                for (int col = tid - 64 + kPre * kOthers; col - lane < later; col += kOthers) {
+                    const u64 hit = __ballot((strip[128 + col] & kp) != 0ull);
+                    if (lane == 0 && hit) s_removed[rb + 2 + (col >> 6)] |= hit;
+                }
             }
             __syncthreads();
         }
