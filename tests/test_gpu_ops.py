@@ -300,8 +300,9 @@ def test_nms_perclass_long_segments(workspace):
 
 
 def test_nms_perclass_segment_not_multiple_of_64_all_kept():
-    """Disjoint boxes (nothing suppressed: the longest walk) in one class, lengths around the block size."""
-    for n in (255, 256, 257, 319, 320, 1025, 2049):
+    """Disjoint boxes (nothing suppressed: the longest walk) in one class, lengths around the block size, the matrix
+    threshold (256) and both ends of the LDS sort's range (512 .. 8192)."""
+    for n in (255, 256, 257, 319, 320, 511, 512, 513, 1025, 2049, 8192, 8193):
         ix = torch.arange(n, dtype=torch.float32)
         bb = torch.stack([ix * 2, torch.zeros(n), ix * 2 + 1, torch.ones(n)], 1)
         sc = torch.rand(n, 1, generator=_gen(n, "all-kept")) + 0.1

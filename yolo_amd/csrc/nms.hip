@@ -691,6 +691,11 @@ __global__ __launch_bounds__(256) void fa_scatter_kernel(const FAArgs a) {
     a.seg[(size_t)img * a.n + fa_class_offset(a.count + (size_t)img * a.nc, c) + slot] = box;
 }
 
+// Segments of kFaSortMin .. kFaSortMax boxes are sorted in LDS by one workgroup (bitonic network on the 64-bit keys:
+// n log^2 n compare-exchanges where counting makes n^2 comparisons); shorter ones, and the rare longer ones, are ranked
+// by counting.
+constexpr int kFaSortMin = 512, kFaSortMax = 8192;
+
 // grid (chunk, class, image): rank of each member inside its class segment.
 // Order: descending score; equal scores: higher box index first (ascending stable sort, reversed).
 __global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
@@ -700,6 +705,7 @@ __global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
     const unsigned cnt = count[c];
     const unsigned m = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x * 256 >= cnt) return;
+    if (cnt >= (unsigned)kFaSortMin && cnt <= (unsigned)kFaSortMax) return;     // fa_sort_kernel's
     const unsigned off = fa_class_offset(count, c);
     const unsigned* seg = a.seg + (size_t)img * a.n + off;
     const float* best = a.best + (size_t)img * a.n;
@@ -724,6 +730,44 @@ __global__ __launch_bounds__(256) void fa_rank_kernel(const FAArgs a) {
     if (m < cnt) {
         a.sorted[(size_t)img * a.n + off + rank] = mybox;
         a.sbox[(size_t)img * a.n + off + rank] = reinterpret_cast<const float4*>(a.boxes)[(size_t)img * a.n + mybox];
+    }
+}
+
+// grid (class, image), 64 KB of dynamic LDS.  Same order as the counting kernel: descending 64-bit key
+// (orderable(score) << 32 | box), keys are unique; the padding up to a power of two carries key 0 and sinks to the end.
+__global__ __launch_bounds__(1024) void fa_sort_kernel(const FAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 s_keys[];
+    const int img = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const unsigned* count = a.count + (size_t)img * a.nc;
+    const int cnt = (int)count[c];
+    if (cnt < kFaSortMin || cnt > kFaSortMax) return;
+    const unsigned off = fa_class_offset(count, c);
+    const unsigned* seg = a.seg + (size_t)img * a.n + off;
+    const float* best = a.best + (size_t)img * a.n;
+    const int P = 1 << (32 - __clz(cnt - 1));          // next power of two >= cnt
+    for (int i = tid; i < P; i += 1024) {
+        u64 key = 0ull;
+        if (i < cnt) {
+            const unsigned b = seg[i];
+            key = ((u64)f2key(best[b]) << 32) | b;
+        }
+        s_keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo + j;
+                const bool desc = (lo & k) == 0;
+                const u64 x = s_keys[lo], y = s_keys[hi];
+                if ((x < y) == desc) { s_keys[lo] = y; s_keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < cnt; i += 1024) {
+        const unsigned b = (unsigned)s_keys[i];
+        a.sorted[(size_t)img * a.n + off + i] = b;
+        a.sbox[(size_t)img * a.n + off + i] = reinterpret_cast<const float4*>(a.boxes)[(size_t)img * a.n + b];
     }
 }
 
@@ -1482,6 +1526,8 @@ extern "C" int ydet_nms_perclass(const float* boxes, const float* scores, int N,
     hipLaunchKernelGGL(fa_score_kernel, dim3(g1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(fa_scatter_kernel, dim3(g1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(fa_rank_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nc, (unsigned)N), dim3(256), 0, s, a);
+    if (n >= kFaSortMin)
+        hipLaunchKernelGGL(fa_sort_kernel, dim3((unsigned)nc, (unsigned)N), dim3(1024), kFaSortMax * sizeof(u64), s, a);
     if (a.mat_words) {
         hipLaunchKernelGGL(fa_plan_kernel, dim3(1), dim3(1024), 0, s, a);
         hipLaunchKernelGGL(fa_matrix_kernel, dim3(2048), dim3(256), 0, s, a);
