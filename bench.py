@@ -129,21 +129,26 @@ def main():
         # What an event adds to the stream, measured before the timed region: the same step alone with and without
         # its events (back-to-back events overstate it: a kernel in between hides part of an event's processing).
         ncal = 9
-        cal_t = lib.ydet_timer_create(n_ops + 1)
-        cal_ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        cal_m = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ncal + 1)]
-        with torch.cuda.stream(streams[0]):
-            for i in range(ncal):
-                cal_m[2 * i].record()
-                step(0)
-                cal_m[2 * i + 1].record()
-                step(0, cal_t, 0, cal_ev)
-            cal_m[2 * ncal].record()
-        torch.cuda.synchronize()
-        diffs = sorted(cal_m[2 * i + 1].elapsed_time(cal_m[2 * i + 2]) - cal_m[2 * i].elapsed_time(cal_m[2 * i + 1])
-                       for i in range(ncal))
-        lib.ydet_timer_destroy(cal_t)
-        event_ms = max(diffs[ncal // 2] / (n_ops + 3), 0.0)      # median over the pairs
+
+        def calibrate():
+            cal_t = lib.ydet_timer_create(n_ops + 1)
+            cal_ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            cal_m = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ncal + 1)]
+            with torch.cuda.stream(streams[0]):
+                for i in range(ncal):
+                    cal_m[2 * i].record()
+                    step(0)
+                    cal_m[2 * i + 1].record()
+                    step(0, cal_t, 0, cal_ev)
+                cal_m[2 * ncal].record()
+            torch.cuda.synchronize()
+            diffs = sorted(cal_m[2 * i + 1].elapsed_time(cal_m[2 * i + 2]) - cal_m[2 * i].elapsed_time(cal_m[2 * i + 1])
+                           for i in range(ncal))
+            lib.ydet_timer_destroy(cal_t)
+            return max(diffs[ncal // 2] / (n_ops + 3), 0.0)      # median over the pairs
+
+        # (a split plan carries no per-op events: its calibration runs with the unsplit plan after the timed region)
+        event_ms = calibrate() if plan_holder["plan"].R == 1 else 0.0
         event_src = "a step alone with its events minus the same step without, per event (median of 9 pairs before the timed region)"
         if args.event_every > 0:
             sampled = [k for k in range(args.steps) if k % args.event_every == 0]   # steps that carry events
@@ -185,6 +190,7 @@ def main():
             model.invalidate_plans()
             step()
             torch.cuda.synchronize()
+            event_ms = calibrate()
             for j in range(n_ev):
                 step(0, timer, j * (n_ops + 1), evs[j])
             torch.cuda.synchronize()
