@@ -42,7 +42,7 @@ typedef enum { YDET_RES_NONE = 0, YDET_RES_AFTER_ACT = 1, YDET_RES_BEFORE_ACT = 
 const char* ydet_last_error(void);
 /* ABI version of the library (bumped when a struct below changes); equals YDET_ABI_VERSION of the header it
  * was built from. */
-#define YDET_ABI_VERSION 15
+#define YDET_ABI_VERSION 16
 int ydet_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -160,6 +160,16 @@ int ydet_focus_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
  * x_up or cout_store.  bf16 weights and output.  Same bf16 intermediate values and accumulation order as the layers run
  * one by one. */
 int ydet_focus_conv_pair_nchw(const ydet_conv_desc* focus, const ydet_conv_desc* next, int x_dtype, void* stream);
+
+/* The first TWO layers of the Darknet-53 / CSPDarknet-53 trunks as one kernel, straight from the NCHW image:
+ * `Conv(3, 32, 3, p=1)` and `Conv(32, 64, 3, p=1, s=2)` (models/basemodel/d19.py:83-123 layer_1, :215-265 layer1; the
+ * Conv of utils/moduleUtils.py:8-24).  The 32-channel map at full image size between them exists only as patches in
+ * LDS.  `first`: x = the image [N, 3, H, W] (x_dtype fp32 or bf16), Cin = 3, 3x3 / stride 1 / pad 1, Cout = 32, w / bias
+ * packed as for ydet_conv2d_nhwc for 16 input channels (the 3 image channels, then zeros; kp = 160), its y is not used;
+ * `next` as for ydet_focus_conv_pair_nchw with H x W the image size (follower and second destination included); both
+ * layers share one activation.  Same bf16 intermediate values and accumulation order as ydet_rgb_conv3x3_nchw followed
+ * by ydet_conv2d_nhwc. */
+int ydet_rgb_conv_pair_nchw(const ydet_conv_desc* first, const ydet_conv_desc* next, int x_dtype, void* stream);
 
 /* The first layer of the Darknet-style trunks straight from the NCHW image: `Conv(3, C, k=3, p=1)` (utils/moduleUtils.py:8-24
  * as used at models/basemodel/d19.py:22,88,133,175,221) including the NCHW -> NHWC edge conversion.  d->x is the image
@@ -455,7 +465,8 @@ typedef enum {
     YDET_OP_BOTTLENECK = 11,/* conv + conv2: as ydet_bottleneck_fused */
     YDET_OP_C3_TAIL = 12,   /* conv + conv2 + conv3: as ydet_c3_tail_fused */
     YDET_OP_RGB_CONV = 13,  /* conv: as ydet_rgb_conv3x3_nchw; iarg3 = image dtype */
-    YDET_OP_FOCUS_PAIR = 14 /* conv + conv2: as ydet_focus_conv_pair_nchw; iarg3 = image dtype */
+    YDET_OP_FOCUS_PAIR = 14,/* conv + conv2: as ydet_focus_conv_pair_nchw; iarg3 = image dtype */
+    YDET_OP_RGB_PAIR = 15   /* conv + conv2: as ydet_rgb_conv_pair_nchw; iarg3 = image dtype */
 } ydet_op_kind;
 
 typedef struct {

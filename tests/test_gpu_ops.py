@@ -748,6 +748,57 @@ def test_focus_pair_fused(shape, tail, src):
     assert rel_err(outs[True].numpy(), ref.numpy()) < 2e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 51, 70), (1, 3, 37, 131), (3, 3, 16, 16), (1, 3, 19, 35)])
+@pytest.mark.parametrize("tail", ["conv", "resblock", "silu", "follower"])
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16, torch.uint8])
+def test_rgb_pair_fused(shape, tail, src):
+    """Conv(3, 32, 3, p=1) -> Conv(32, 64, 3, p=1, s=2) [-> resblock(64) | -> Conv(64, 48, 1) riding as a follower], the opening of the Darknet-53 / CSPDarknet-53
+    trunks (models/basemodel/d19.py:83-123, :215-265): odd and even image sizes, sizes that are not multiples of the
+    8 x 16 output patch, fp32 / bf16 / uint8 (converted on the host) images.  The fused launch against the two layers
+    run one by one (same bf16 intermediate values and accumulation order) and against torch fp32."""
+    from yolo_amd.utils.moduleUtils import Conv, resblock
+    from yolo_amd.synthetic import init_deterministic
+    mods = [Conv(3, 32, 3, p=1), Conv(32, 64, 3, p=1, s=2)] + ([resblock(64, nblocks=1)] if tail == "resblock" else [])
+    if tail == "silu":
+        mods[0].conv[2] = nn.SiLU()
+        mods[1].conv[2] = nn.SiLU()
+    if tail == "follower":
+        mods.append(Conv(64, 48, 1))
+    net = nn.Sequential(*mods)
+    init_deterministic(net, seed=13)
+    net.eval()
+    gen = _gen(23, f"rgbpair{shape}")
+    if src == torch.uint8:
+        x = torch.randint(0, 256, shape, generator=gen, dtype=torch.uint8)
+        xf = x.float() / 255.0
+    else:
+        x = torch.randn(*shape, generator=gen).to(src)
+        xf = x.float()
+    with torch.no_grad():
+        ref = net(xf)
+    net = net.to(DEV)
+    outs = {}
+    for fused in (True, False):
+        engine.set_focus_pair_fusion(fused)
+        try:
+            g = engine.Graph(DEV, "bf16")
+            t = g.input_nchw(*shape)
+            for m in mods:
+                t = m.lower(g, t)
+            g.to_nchw(t, "y")
+            plan = g.finalize()
+            kinds = [k for k, _ in g.ops]
+            assert kinds[0] == ("focus_pair" if fused else "rgb_conv"), kinds
+            assert (plan.op_lists[0][0].kind == _ffi.OP_RGB_PAIR) == fused
+            outs[fused] = plan.run(x.to(DEV))["y"].float().cpu()
+        finally:
+            engine.set_focus_pair_fusion(True)
+    assert outs[True].shape == ref.shape
+    assert rel_err(outs[True].numpy(), outs[False].numpy()) < 1e-2
+    assert (outs[True] != outs[False]).float().mean() < 0.02
+    assert rel_err(outs[True].numpy(), ref.numpy()) < 2e-2
+
+
 # ---- 32-channel bottleneck as one kernel ---------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 32, 16, 64), (1, 32, 13, 37), (3, 32, 40, 40), (1, 32, 5, 3),
                                    (2, 64, 16, 32), (1, 64, 13, 37), (3, 64, 40, 40), (1, 64, 5, 3)])

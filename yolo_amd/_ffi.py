@@ -14,9 +14,9 @@ F32, BF16, U8 = 0, 1, 2   # U8: output dtype of ydet_preprocess_u8 only
 ACT_NONE, ACT_LEAKY, ACT_SILU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 (OP_CONV, OP_MAXPOOL2, OP_MAXPOOL2S1, OP_SPP, OP_UPSAMPLE, OP_SPACE2DEPTH, OP_COPY, OP_NCHW2NHWC,
- OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK, OP_C3_TAIL, OP_RGB_CONV, OP_FOCUS_PAIR) = range(15)
+ OP_NHWC2NCHW, OP_FOCUS_CONV, OP_HEAD_DECODE, OP_BOTTLENECK, OP_C3_TAIL, OP_RGB_CONV, OP_FOCUS_PAIR, OP_RGB_PAIR) = range(16)
 MAX_ANCHORS = 8
-ABI_VERSION = 15   # YDET_ABI_VERSION of include/ydet.h these structs were written against
+ABI_VERSION = 16   # YDET_ABI_VERSION of include/ydet.h these structs were written against
 
 
 class ConvDesc(C.Structure):
@@ -99,6 +99,7 @@ SYMBOLS = {
     "ydet_focus_conv3x3_nchw": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_focus_conv_pair_nchw": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_rgb_conv3x3_nchw": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
+    "ydet_rgb_conv_pair_nchw": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_maxpool2x2_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
     "ydet_maxpool2x2s1_zeropad_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),
     "ydet_spp_nhwc": (C.c_int, [C.POINTER(SliceDesc), C.c_void_p]),

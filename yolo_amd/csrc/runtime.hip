@@ -94,7 +94,8 @@ static int launch_op(const ydet_op& op, hipStream_t s) {
     switch (op.kind) {
         case YDET_OP_CONV: return ydet_launch_conv(&op.conv, s);
         case YDET_OP_FOCUS_CONV: return ydet_launch_focus_conv(&op.conv, op.iarg3, s);
-        case YDET_OP_FOCUS_PAIR: return ydet_launch_focus_pair(&op.conv, &op.conv2, op.iarg3, s);
+        case YDET_OP_FOCUS_PAIR: return ydet_launch_focus_pair(&op.conv, &op.conv2, op.iarg3, s, false);
+        case YDET_OP_RGB_PAIR: return ydet_launch_focus_pair(&op.conv, &op.conv2, op.iarg3, s, true);
         case YDET_OP_RGB_CONV: return ydet_launch_rgb_conv(&op.conv, op.iarg3, s);
         case YDET_OP_HEAD_DECODE: return ydet_launch_head_decode(&op.conv, &op.head, s);
         case YDET_OP_BOTTLENECK: return ydet_launch_bottleneck(&op.conv, &op.conv2, nullptr, s);

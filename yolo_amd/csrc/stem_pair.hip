@@ -13,6 +13,11 @@
 //   P3  optional 1x1 follower: the finished 128 x 64 tile goes through LDS (144-byte pitch) once more
 // Every LDS pitch is an odd number of 16-byte chunks: sixteen consecutive pixels at one channel offset fall on sixteen
 // different bank groups without any swizzle, and every tap offset is an immediate.
+//
+// RGB variant (the Darknet-style trunks of the v3 / v4 detectors, models/basemodel/d19.py:83-123 and :215-265, whose first
+// two layers are Conv(3, 32, 3, p=1) and Conv(32, 64, 3, p=1, s=2)): no slicing, F holds the 19 x 35 image pixels
+// themselves (3 channels + 13 zeros per slot, weights packed the same way: k = tap * 16 + channel), everything from P1
+// on is shared.  The 32-channel map at FULL image size -- 1.5 GB for 64 images of 608 x 608 -- is never written.
 #include <type_traits>
 
 #include "ydet_internal.h"
@@ -93,8 +98,9 @@ __device__ __forceinline__ bf16x8 finish8(const f32x4& lo, const f32x4& hi, cons
     return o;
 }
 
-template <typename TX, bool FOLLOW, bool SILU0, bool SILU1>
+template <typename TX, bool FOLLOW, bool SILU0, bool SILU1, bool RGB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void focus_pair_kernel(const PairArgs a) {
+    static_assert(!RGB || !std::is_same<TX, uint8_t>::value, "raw pixel values: Focus variant only");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     __shared__ __bf16 lut[std::is_same<TX, uint8_t>::value ? 256 : 1];
     if constexpr (std::is_same<TX, uint8_t>::value) lut[threadIdx.x] = (__bf16)((float)threadIdx.x / 255.0f);
@@ -106,15 +112,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int tx = bid % a.tiles_x, ty = bid / a.tiles_x, n = blockIdx.y;
     const int oi0 = ty * T_H, oj0 = tx * T_W;                // first output pixel
     const int ar0 = 2 * oi0 - 1, ac0 = 2 * oj0 - 1;          // first pixel of A (in the first convolution's output map)
-    const int Y0 = 2 * (ar0 - 1), X0 = 2 * (ac0 - 1);        // first image pixel
+    const int Y0 = RGB ? ar0 - 1 : 2 * (ar0 - 1), X0 = RGB ? ac0 - 1 : 2 * (ac0 - 1);        // first image pixel
 
     // ---- P0: image patch -> F.  A thread builds whole focus pixels (2 x 2 image pixels x 3 channels = six 2-pixel loads)
     constexpr int ITER = (F_N + 255) / 256;
-    pair_t px[ITER][6];
+    pair_t px[RGB ? 1 : ITER][6];
+    TX px1[RGB ? ITER : 1][3];          // RGB variant: a thread fetches single pixels, three channels each
     const TX* img = reinterpret_cast<const TX*>(a.x) + (size_t)n * 3 * a.H * a.W;
     // (offsets inside one image fit 32 bits -- checked on the host -- and the image base is uniform)
-    const bool interior0 = Y0 >= 0 && Y0 + 2 * F_H <= a.H && X0 >= 0 && X0 + 2 * F_W <= a.W;   // workgroup-uniform
-    if (interior0) {
+    const bool interior0 = RGB ? Y0 >= 0 && Y0 + F_H <= a.H && X0 >= 0 && X0 + F_W <= a.W
+                               : Y0 >= 0 && Y0 + 2 * F_H <= a.H && X0 >= 0 && X0 + 2 * F_W <= a.W;   // workgroup-uniform
+    if constexpr (RGB) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int fp = tid + 256 * it;
+            const int fq = min(fp, F_N - 1);
+            const int fy = fq / F_W, fx = fq - fy * F_W;
+            const int Y = Y0 + fy, X = X0 + fx;
+            const bool ok = interior0 || (fp < F_N && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                px1[it][c] = TX();
+                if (ok) px1[it][c] = img[(unsigned)(c * a.H + Y) * (unsigned)a.W + (unsigned)X];
+            }
+        }
+    } else if (interior0) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int fp = min(tid + 256 * it, F_N - 1);
@@ -161,6 +183,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int it = 0; it < ITER; ++it) {
         const int fp = tid + 256 * it;
         if (fp >= F_N) continue;
+        if constexpr (RGB) {
+            bf16x8 lo = bf16x8{};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lo[c] = (__bf16)(float)px1[it][c];
+            *reinterpret_cast<bf16x8*>(lds + fp * F_PITCH) = lo;
+            *reinterpret_cast<bf16x8*>(lds + fp * F_PITCH + 16) = bf16x8{};
+            continue;
+        }
         __bf16 ch[12];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -316,30 +346,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
-template <typename TX, bool FOLLOW>
+template <typename TX, bool FOLLOW, bool RGB = false>
 void launch_acts(const PairArgs& a, dim3 grid, hipStream_t s) {
     const bool s0 = a.act0 == YDET_ACT_SILU, s1 = a.act1 == YDET_ACT_SILU;
-    if (s0 && s1) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, true, true>), grid, dim3(256), 0, s, a);
-    else if (!s0 && !s1) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, false, false>), grid, dim3(256), 0, s, a);
-    else if (s0) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, false, true>), grid, dim3(256), 0, s, a);
+    if (s0 && s1) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, true, true, RGB>), grid, dim3(256), 0, s, a);
+    else if (!s0 && !s1) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, false, false, RGB>), grid, dim3(256), 0, s, a);
+    else if (s0) hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, true, false, RGB>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((focus_pair_kernel<TX, FOLLOW, false, true, RGB>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace
 
-int ydet_launch_focus_pair(const ydet_conv_desc* f, const ydet_conv_desc* d, int x_dtype, hipStream_t stream) {
+int ydet_launch_focus_pair(const ydet_conv_desc* f, const ydet_conv_desc* d, int x_dtype, hipStream_t stream, bool rgb) {
     YDET_CHECK_ARG(f != nullptr && d != nullptr && f->x && f->w && f->bias && d->w && d->bias && d->y, "focus_pair: null pointer");
-    YDET_CHECK_ARG(dtype_ok(x_dtype) || x_dtype == YDET_U8, "focus_pair: bad image dtype");
+    YDET_CHECK_ARG(dtype_ok(x_dtype) || (x_dtype == YDET_U8 && !rgb), "focus_pair: bad image dtype");
     YDET_CHECK_ARG(f->groups <= 1 && f->dilation <= 1 && d->groups <= 1 && d->dilation <= 1, "focus_pair: plain convolutions only");
     YDET_CHECK_ARG(f->in_dtype == YDET_BF16 && d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "focus_pair: bf16 weights and output only");
-    YDET_CHECK_ARG(f->N > 0 && f->N <= 65535 && f->H > 0 && f->W > 0 && f->H % 2 == 0 && f->W % 2 == 0,
+    YDET_CHECK_ARG(f->N > 0 && f->N <= 65535 && f->H > 0 && f->W > 0 && (rgb || (f->H % 2 == 0 && f->W % 2 == 0)),
                    "focus_pair: image %d x %d x %d", f->N, f->H, f->W);
     YDET_CHECK_ARG(f->Cin == 3 && f->KH == 3 && f->KW == 3 && f->stride == 1 && f->pad == 1 && f->Cout == 32 && f->kp == KSTEPS0 * 32,
                    "focus_pair: first layer must be Focus + 3x3 / stride 1 / pad 1 with 32 output channels (kp = %d)", KSTEPS0 * 32);
     YDET_CHECK_ARG(f->res == nullptr && f->post_scale == nullptr && f->y2 == nullptr && f->pw_w == nullptr,
                    "focus_pair: first layer: no residual / second stage / destination / follower");
     YDET_CHECK_ARG(3LL * f->H * f->W < (1LL << 31), "focus_pair: image of %d x %d pixels", f->H, f->W);
-    const int H1 = f->H / 2, W1 = f->W / 2;
+    const int H1 = rgb ? f->H : f->H / 2, W1 = rgb ? f->W : f->W / 2;
+    YDET_CHECK_ARG(!rgb || f->act == d->act, "rgb_pair: both layers share one activation");
     YDET_CHECK_ARG(d->N == f->N && d->H == H1 && d->W == W1 && d->Cin == 32 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 &&
                        d->Cout == 64 && d->kp == 288 && d->cout_pad >= 64,
                    "focus_pair: second layer must be 3x3 / stride 2 / pad 1, 32 -> 64 channels on the %d x %d map", H1, W1);
@@ -373,7 +404,14 @@ int ydet_launch_focus_pair(const ydet_conv_desc* f, const ydet_conv_desc* d, int
     a.act1 = d->act; a.slope1 = d->act == YDET_ACT_NONE ? 1.0f : d->slope;
     a.pw_rows = d->pw_w ? d->pw_cout : 0;
     const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)a.N);
-    if (d->pw_w) {
+    if (rgb) {      // (instantiated for the activation pairs the Darknet trunks use: both SiLU or both leaky / none)
+        const bool silu = a.act0 == YDET_ACT_SILU, follow = d->pw_w != nullptr, f32 = x_dtype == YDET_F32;
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, a); };
+        if (f32 && follow) silu ? go(focus_pair_kernel<float, true, true, true, true>) : go(focus_pair_kernel<float, true, false, false, true>);
+        else if (f32) silu ? go(focus_pair_kernel<float, false, true, true, true>) : go(focus_pair_kernel<float, false, false, false, true>);
+        else if (follow) silu ? go(focus_pair_kernel<__bf16, true, true, true, true>) : go(focus_pair_kernel<__bf16, true, false, false, true>);
+        else silu ? go(focus_pair_kernel<__bf16, false, true, true, true>) : go(focus_pair_kernel<__bf16, false, false, false, true>);
+    } else if (d->pw_w) {
         if (x_dtype == YDET_F32) launch_acts<float, true>(a, grid, stream);
         else if (x_dtype == YDET_U8) launch_acts<uint8_t, true>(a, grid, stream);
         else launch_acts<__bf16, true>(a, grid, stream);
@@ -388,5 +426,10 @@ int ydet_launch_focus_pair(const ydet_conv_desc* f, const ydet_conv_desc* d, int
 
 extern "C" int ydet_focus_conv_pair_nchw(const ydet_conv_desc* focus, const ydet_conv_desc* next, int x_dtype, void* stream) {
     clear_error();
-    return ydet_launch_focus_pair(focus, next, x_dtype, as_stream(stream));
+    return ydet_launch_focus_pair(focus, next, x_dtype, as_stream(stream), false);
+}
+
+extern "C" int ydet_rgb_conv_pair_nchw(const ydet_conv_desc* first, const ydet_conv_desc* next, int x_dtype, void* stream) {
+    clear_error();
+    return ydet_launch_focus_pair(first, next, x_dtype, as_stream(stream), true);
 }

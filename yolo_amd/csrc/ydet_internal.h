@@ -93,6 +93,6 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 int ydet_launch_conv(const ydet_conv_desc* d, hipStream_t stream);
 int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, hipStream_t stream);
 int ydet_launch_focus_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream);
-int ydet_launch_focus_pair(const ydet_conv_desc* focus, const ydet_conv_desc* next, int x_dtype, hipStream_t stream);
+int ydet_launch_focus_pair(const ydet_conv_desc* focus, const ydet_conv_desc* next, int x_dtype, hipStream_t stream, bool rgb);
 int ydet_launch_rgb_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t stream);
 int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, const ydet_conv_desc* c3 /* or null */, hipStream_t stream);

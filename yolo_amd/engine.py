@@ -517,7 +517,7 @@ class Graph:
             npc = PackedConv(w4.contiguous(), b4, 4, pc.Cout, 3, 3, 64, w4.shape[0], cin_real=3)
             self.keep.append(npc)
             self.ops[idx] = ("rgb_conv", dict(y=y, pc=npc, N=e["N"], C=3, H=e["H"], W=e["W"], act=A["act"], slope=A["slope"],
-                                              src_dtype=e["src_dtype"]))
+                                              src_dtype=e["src_dtype"], pc_src=pc))
             j = next(i for i, (_, r) in enumerate(self.ops) if r is A)
             del self.ops[j]
             self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
@@ -526,7 +526,9 @@ class Graph:
     def fuse_focus_pair(self):
         """A fused Focus layer with 32 output channels whose map is read by exactly one op, a plain 3x3 / stride 2 / pad 1
         convolution to 64 channels (on its own or carrying a 1x1 follower): both become one "focus_pair" op and the
-        32-channel map in between -- the largest tensor of a YOLOv5 forward pass -- is never written."""
+        32-channel map in between -- the largest tensor of a YOLOv5 forward pass -- is never written.  Likewise the fused
+        3-channel first layer of the Darknet-53 / CSPDarknet-53 trunks (32 output channels at full image size) and the
+        stride-2 convolution behind it (no follower there)."""
         if not _fuse_focus_pair or self.dt != _ffi.BF16:
             return
 
@@ -545,8 +547,9 @@ class Graph:
             return ts
 
         for idx, (kind, e) in enumerate(list(self.ops)):
-            if kind != "focus_conv" or e["pc"].Cout != 32:
+            if kind not in ("focus_conv", "rgb_conv") or e["pc"].Cout != 32:
                 continue
+            rgb = kind == "rgb_conv"
             root, off = e["y"].resolve()
             if root.external or not e["y"].whole() or any(v.resolve()[0] is root for v in self.outputs.values() if isinstance(v, T)):
                 continue
@@ -565,8 +568,20 @@ class Graph:
                 continue
             if pre is not None and not (B["pc"].Cout % 8 == 0 and B["pc"].Cout <= 64 and B["pc"].kp == 64):
                 continue
+            if rgb and e["act"] != B["act"]:
+                continue
+            if rgb:      # the pair kernel reads 16-channel pixel slots: k = tap * 16 + channel
+                src = e["pc_src"]
+                rows = max(src.cout_pad, 32)
+                w16 = torch.zeros(rows, 10, 16, device=src.w.device, dtype=src.w.dtype)
+                w16[:src.cout_pad, :9, :3] = src.w[:, :9 * src.Cin].reshape(src.cout_pad, 9, src.Cin)[:, :, :3]
+                b16 = torch.zeros(rows, device=src.b.device)
+                b16[:src.cout_pad] = src.b
+                npc = PackedConv(w16.reshape(rows, 160).contiguous(), b16, 16, 32, 3, 3, 160, rows, cin_real=3)
+                self.keep.append(npc)
+                e = dict(e, pc=npc)
             j = next(i for i, (_, r) in enumerate(self.ops) if r is B)
-            self.ops[idx] = ("focus_pair", dict(focus=e, conv=B))
+            self.ops[idx] = ("focus_pair", dict(focus=e, conv=B, rgb=rgb))
             root.dead = True          # never written, never read: no memory behind it
             del self.ops[j]
             self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
@@ -668,8 +683,8 @@ class Plan:
         elif kind == "focus_pair":
             assert not a["conv"]["y"].resolve()[0].external
             self._fill_conv(op, i, a["conv"], arena, record, d=op.conv2, skip_x=True)
-            self._fill(op, i, "focus_conv", a["focus"], arena, record, with_y=False)
-            op.kind = _ffi.OP_FOCUS_PAIR
+            self._fill(op, i, "rgb_conv" if a["rgb"] else "focus_conv", a["focus"], arena, record, with_y=False)
+            op.kind = _ffi.OP_RGB_PAIR if a["rgb"] else _ffi.OP_FOCUS_PAIR
         elif kind in ("focus_conv", "rgb_conv"):
             op.kind = _ffi.OP_FOCUS_CONV if kind == "focus_conv" else _ffi.OP_RGB_CONV
             d, pc = op.conv, a["pc"]
@@ -780,7 +795,7 @@ class Plan:
                for st in self._ext_storages}
         for i, x in zip(self.patch_in, xs):
             op0 = self.op_lists[0][i]
-            focus = op0.kind in (_ffi.OP_FOCUS_CONV, _ffi.OP_RGB_CONV, _ffi.OP_FOCUS_PAIR)   # first layers that read the image themselves
+            focus = op0.kind in (_ffi.OP_FOCUS_CONV, _ffi.OP_RGB_CONV, _ffi.OP_FOCUS_PAIR, _ffi.OP_RGB_PAIR)   # first layers that read the image themselves
             if x.dtype == torch.uint8:
                 # raw pixel values: the fused Focus layer scales them by 1/255 while loading (val.py:68-69 folded in);
                 # any other first layer gets the scaled fp32 image
@@ -999,12 +1014,13 @@ def _op_info(kind, a):
         f, B = a["focus"], a["conv"]
         pre, y = B.get("pre"), B["y"]
         pa = pre["pc"] if pre else B["pc"]
-        px1, px2 = f["N"] * (f["H"] // 2) * (f["W"] // 2), y.N * y.H * y.W
+        rgb = a.get("rgb", False)
+        px1, px2 = (f["N"] * f["H"] * f["W"] if rgb else f["N"] * (f["H"] // 2) * (f["W"] // 2)), y.N * y.H * y.W
         cout = B["pc"].Cout
-        flops = 2.0 * px1 * 32 * 4 * f["C"] * 9 + 2.0 * px2 * 64 * 32 * 9 + (2.0 * px2 * cout * 64 if pre else 0.0)
+        flops = 2.0 * px1 * 32 * (1 if rgb else 4) * f["C"] * 9 + 2.0 * px2 * 64 * 32 * 9 + (2.0 * px2 * cout * 64 if pre else 0.0)
         nbytes = f["N"] * f["C"] * f["H"] * f["W"] * 4 + px2 * cout * 2 + (32 * 160 + 64 * 288 + (cout * 64 if pre else 0)) * 2
-        return dict(kind="conv", label="conv_focus_pair", flops=flops, bytes=nbytes,
-                    shape=(f["N"], f["H"], f["W"], f["C"], cout, 3, 4))
+        return dict(kind="conv", label="conv_rgb_pair" if rgb else "conv_focus_pair", flops=flops, bytes=nbytes,
+                    shape=(f["N"], f["H"], f["W"], f["C"], cout, 3, 2 if rgb else 4))
     if kind == "focus_conv":
         y, pc = a["y"], a["pc"]
         return dict(kind="conv", label="conv_focus3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 4 * a["C"] * 9,
