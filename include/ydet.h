@@ -175,7 +175,10 @@ int ydet_rgb_conv_pair_nchw(const ydet_conv_desc* first, const ydet_conv_desc* n
  * as used at models/basemodel/d19.py:22,88,133,175,221) including the NCHW -> NHWC edge conversion.  d->x is the image
  * [N, 3, H, W] (x_dtype fp32 or bf16, contiguous), d->Cin = 3; 3x3 / stride 1 / pad 1; w / bias packed as for
  * ydet_conv2d_nhwc for 4 input channels (the 3 image channels + a zero; kp = 64); d->y is the NHWC bf16 slice
- * [N, H, W, Cout], Cout a multiple of 8, <= 64.  bf16 weights / output only; x_ld, x_coff, res, post_* unused. */
+ * [N, H, W, Cout], Cout a multiple of 8, <= 64.  bf16 weights / output only; x_ld, x_coff, res, post_* unused.
+ * Pooled form: with H and W even and Ho x Wo = H/2 x W/2 the MaxPool2d(2, 2) that follows the layer in the Darknet-19
+ * and tiny trunks (models/basemodel/d19.py:29 conv1, :175-182 conv_1 / maxpool_1) is taken in the epilogue and d->y is
+ * the pooled slice [N, H/2, W/2, Cout] (the result of the two launches, bit for bit). */
 int ydet_rgb_conv3x3_nchw(const ydet_conv_desc* d, int x_dtype, void* stream);
 
 /* A residual bottleneck with C = 32 or 64 channels throughout as ONE kernel: yolov5_official/modules.py:208-218,

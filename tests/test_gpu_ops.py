@@ -799,6 +799,41 @@ def test_rgb_pair_fused(shape, tail, src):
     assert rel_err(outs[True].numpy(), ref.numpy()) < 2e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 50, 70), (1, 3, 36, 130), (3, 3, 16, 16), (1, 3, 18, 34)])
+@pytest.mark.parametrize("cout", [16, 32, 64])
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
+def test_rgb_stem_pool_fused(shape, cout, src):
+    """Conv(3, C, 3, p=1) -> MaxPool2d(2, 2) -> Conv(C, 2C, 3, p=1): the opening of the Darknet-19 / tiny trunks
+    (models/basemodel/d19.py:29, :175-182).  The pool taken in the first layer's epilogue equals the two launches bit for
+    bit (max commutes with the rounding to bf16); both against torch fp32."""
+    from yolo_amd.utils.moduleUtils import Conv
+    from yolo_amd.synthetic import init_deterministic
+    net = nn.Sequential(nn.Sequential(Conv(3, cout, 3, p=1), nn.MaxPool2d(2, 2)), Conv(cout, 2 * cout, 3, p=1))
+    init_deterministic(net, seed=17)
+    net.eval()
+    x = torch.randn(*shape, generator=_gen(29, f"rgbpool{shape}")).to(src)
+    with torch.no_grad():
+        ref = net(x.float())
+    net = net.to(DEV)
+    outs = {}
+    for fused in (True, False):
+        engine.set_rgb_pool_fusion(fused)
+        try:
+            g = engine.Graph(DEV, "bf16")
+            t = engine.lower_any(g, net, g.input_nchw(*shape))
+            g.to_nchw(t, "y")
+            plan = g.finalize()
+            kinds = [k for k, _ in g.ops]
+            assert kinds[0] == "rgb_conv" and ("maxpool2" in kinds) == (not fused), kinds
+            assert (plan.op_lists[0][0].conv.Ho == shape[2] // 2) == fused
+            outs[fused] = plan.run(x.to(DEV))["y"].float().cpu()
+        finally:
+            engine.set_rgb_pool_fusion(True)
+    assert outs[True].shape == ref.shape
+    assert torch.equal(outs[True], outs[False])
+    assert rel_err(outs[True].numpy(), ref.numpy()) < 2e-2
+
+
 # ---- 32-channel bottleneck as one kernel ---------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 32, 16, 64), (1, 32, 13, 37), (3, 32, 40, 40), (1, 32, 5, 3),
                                    (2, 64, 16, 32), (1, 64, 13, 37), (3, 64, 40, 40), (1, 64, 5, 3)])

@@ -28,6 +28,7 @@ struct StemArgs {
     int tiles_x, tiles_y;
     int act;
     float slope;
+    int Hp, Wp;         // rgb_conv3x3_kernel<.., POOL>: size of the pooled map that is written
 };
 
 template <typename TX>
@@ -206,7 +207,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FN == 2 ? 5
 // P[340][4] bf16 (3 channels + a zero, 8 bytes), K is tap-major with 4 channels per tap (k = tap*4 + c: 36 -> 64 = two
 // K steps), so a lane's 8 k-values are two taps = two 8-byte LDS reads.  As the generic convolution this layer ran on
 // channel-padded NHWC input behind a layout kernel and was the slowest launch of every one of those networks.
-template <typename TX, int FN>
+// POOL: the MaxPool2d(2, 2) that follows the layer in the Darknet-19 and tiny trunks (models/basemodel/d19.py:29, :175-182)
+// is taken in the epilogue -- a lane holds both rows of its column, the neighbouring column is the neighbouring lane --
+// and only the pooled map (a quarter of the bytes) is written.  max commutes with the rounding to bf16, so the result
+// is that of the two launches.
+template <typename TX, int FN, bool POOL = false>
 __global__ __launch_bounds__(256) void rgb_conv3x3_kernel(const StemArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 P[FH * FW * 4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -264,6 +269,39 @@ __global__ __launch_bounds__(256) void rgb_conv3x3_kernel(const StemArgs a) {
     }
 
     const bool silu = a.act == YDET_ACT_SILU;
+    if constexpr (POOL) {
+        const int pi = (i0 >> 1) + wave;                       // rows 2 wave and 2 wave + 1 of the tile -> one pooled row
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int pj = (j0 >> 1) + 8 * jj + (p >> 1);      // columns p and p ^ 1 -> one pooled column (even lanes store)
+#pragma unroll
+            for (int h = 0; h < FN / 2; ++h) {
+                const int co = 32 * h + 8 * g;
+                float m[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float top = e < 4 ? acc[2 * h][jj][e] : acc[2 * h + 1][jj][e - 4];
+                    float bot = e < 4 ? acc[2 * h][jj + 2][e] : acc[2 * h + 1][jj + 2][e - 4];
+                    if (a.bias && co < a.Cout) { const float b = a.bias[co + e]; top += b; bot += b; }
+                    if (silu) {
+                        top = top * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(top * -1.44269504088896340736f));
+                        bot = bot * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(bot * -1.44269504088896340736f));
+                    } else {
+                        top = top > 0.f ? top : top * a.slope;
+                        bot = bot > 0.f ? bot : bot * a.slope;
+                    }
+                    const float v = fmaxf(top, bot);
+                    m[e] = fmaxf(v, __shfl_xor(v, 1));
+                }
+                if ((p & 1) || pi >= a.Hp || pj >= a.Wp || co >= a.Cout) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)m[e];
+                *reinterpret_cast<bf16x8*>(a.y + ((((size_t)n * a.Hp + pi) * a.Wp + pj) * a.y_ld + a.y_coff + co) * 2) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int oi = i0 + 2 * wave + (j >> 1), oj = j0 + 16 * (j & 1) + p;
@@ -303,8 +341,9 @@ int ydet_launch_rgb_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t strea
     YDET_CHECK_ARG(dtype_ok(x_dtype), "rgb_conv3x3: bad image dtype");
     YDET_CHECK_ARG(d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "rgb_conv3x3: bf16 weights and output only");
     YDET_CHECK_ARG(d->N > 0 && d->N <= 65535 && d->H > 0 && d->W > 0, "rgb_conv3x3: image %d x %d x %d", d->N, d->H, d->W);
-    YDET_CHECK_ARG(d->Cin == 3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->H && d->Wo == d->W,
-                   "rgb_conv3x3: 3 image channels and a 3x3 / stride 1 / pad 1 convolution only");
+    const bool pool = d->H % 2 == 0 && d->W % 2 == 0 && d->Ho == d->H / 2 && d->Wo == d->W / 2;   // the 2x2 / stride 2 max pool folded in
+    YDET_CHECK_ARG(d->Cin == 3 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && (pool || (d->Ho == d->H && d->Wo == d->W)),
+                   "rgb_conv3x3: 3 image channels and a 3x3 / stride 1 / pad 1 convolution only (Ho x Wo = H x W, or H/2 x W/2 for the pooled form)");
     YDET_CHECK_ARG(d->Cout >= 8 && d->Cout <= 64 && d->Cout % 8 == 0 && d->cout_pad >= 64, "rgb_conv3x3: Cout=%d (multiple of 8, <= 64)", d->Cout);
     YDET_CHECK_ARG(d->kp == 64, "rgb_conv3x3: weights must be packed for 4 input channels per tap (kp = 64)");
     YDET_CHECK_ARG(d->y_ld % 8 == 0 && d->y_coff % 8 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->y_ld,
@@ -314,13 +353,22 @@ int ydet_launch_rgb_conv(const ydet_conv_desc* d, int x_dtype, hipStream_t strea
                        ((uintptr_t)d->bias & 15) == 0, "rgb_conv3x3: pointer alignment");
     StemArgs a;
     a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->H; a.Wo = d->W; a.Cout = d->Cout; a.y_ld = d->y_ld; a.y_coff = d->y_coff;
+    a.Hp = d->Ho; a.Wp = d->Wo;
     a.tiles_x = (a.Wo + TW - 1) / TW; a.tiles_y = (a.Ho + TH - 1) / TH;
     a.act = d->act;
     a.slope = d->act == YDET_ACT_NONE ? 1.0f : d->slope;
     const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)a.N);
     const bool wide = d->Cout > 32;
-    if (x_dtype == YDET_F32) {
+    if (pool) {
+        if (x_dtype == YDET_F32) {
+            if (wide) hipLaunchKernelGGL((rgb_conv3x3_kernel<float, 4, true>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((rgb_conv3x3_kernel<float, 2, true>), grid, dim3(256), 0, stream, a);
+        } else {
+            if (wide) hipLaunchKernelGGL((rgb_conv3x3_kernel<__bf16, 4, true>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((rgb_conv3x3_kernel<__bf16, 2, true>), grid, dim3(256), 0, stream, a);
+        }
+    } else if (x_dtype == YDET_F32) {
         if (wide) hipLaunchKernelGGL((rgb_conv3x3_kernel<float, 4>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((rgb_conv3x3_kernel<float, 2>), grid, dim3(256), 0, stream, a);
     } else {

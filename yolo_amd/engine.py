@@ -522,6 +522,40 @@ class Graph:
             del self.ops[j]
             self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
 
+    # ---- 3-channel first layer + the 2x2 max pool behind it ---------------------------------------------------------------
+    def fuse_rgb_pool(self):
+        """An "rgb_conv" op whose map (even height and width) is read by exactly one op, a 2x2 / stride 2 max pool: the pool
+        is taken in the convolution's epilogue and the full-size map is never written."""
+        if not _fuse_rgb_pool or self.dt != _ffi.BF16:
+            return
+        for idx, (kind, e) in enumerate(list(self.ops)):
+            if kind != "rgb_conv" or e["H"] % 2 or e["W"] % 2 or e.get("pool"):
+                continue
+            root, off = e["y"].resolve()
+            if root.external or not e["y"].whole() or any(v.resolve()[0] is root for v in self.outputs.values() if isinstance(v, T)):
+                continue
+            readers = []
+            for k2, a2 in self.ops:
+                ts = [a2[key] for key in ("x", "res", "other") if isinstance(a2.get(key), T)]
+                if k2 in ("bottleneck", "c3tail"):
+                    ts.append(a2["cv1"]["x"])
+                if a2.get("up") is not None:
+                    ts.append(a2["up"][0])
+                if a2.get("pre") is not None:
+                    ts.append(a2["pre"]["x"])
+                if a2 is not e and any(t.resolve()[0] is root for t in ts):
+                    readers.append((k2, a2))
+            if len(readers) != 1 or readers[0][0] != "maxpool2":
+                continue
+            P = readers[0][1]
+            if P["x"].resolve() != (root, off) or P["x"].C != e["y"].C or P["y"].dtype != _ffi.BF16:
+                continue
+            e["y"], e["pool"] = P["y"], True
+            root.dead = True
+            j = next(i for i, (_, r) in enumerate(self.ops) if r is P)
+            del self.ops[j]
+            self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
+
     # ---- Focus layer + the stride-2 convolution behind it as one kernel ---------------------------------------------------
     def fuse_focus_pair(self):
         """A fused Focus layer with 32 output channels whose map is read by exactly one op, a plain 3x3 / stride 2 / pad 1
@@ -550,6 +584,8 @@ class Graph:
             if kind not in ("focus_conv", "rgb_conv") or e["pc"].Cout != 32:
                 continue
             rgb = kind == "rgb_conv"
+            if rgb and e.get("pool"):
+                continue
             root, off = e["y"].resolve()
             if root.external or not e["y"].whole() or any(v.resolve()[0] is root for v in self.outputs.values() if isinstance(v, T)):
                 continue
@@ -606,6 +642,7 @@ class Plan:
         g.fuse_upsamples()
         g.fuse_pointwise_followers()
         g.fuse_rgb_stem()
+        g.fuse_rgb_pool()
         g.fuse_focus_pair()
         n = len(g.ops)
         self.patch_in = list(g.ext_in)  # op indices whose source is a caller-supplied NCHW input
@@ -693,7 +730,7 @@ class Plan:
             d.w, d.bias = pc.w.data_ptr(), pc.b.data_ptr()
             d.N, d.H, d.W, d.Cin = a["N"], a["H"], a["W"], a["C"]
             d.Cout, d.KH, d.KW, d.stride, d.pad = pc.Cout, 3, 3, 1, 1
-            d.Ho, d.Wo = (a["H"] // 2, a["W"] // 2) if kind == "focus_conv" else (a["H"], a["W"])
+            d.Ho, d.Wo = (a["H"] // 2, a["W"] // 2) if kind == "focus_conv" or a.get("pool") else (a["H"], a["W"])
             d.y_ld, d.y_coff, d.kp, d.cout_pad = root.ld, off, pc.kp, pc.cout_pad
             d.act, d.slope, d.in_dtype, d.out_dtype = a["act"], a["slope"], _ffi.BF16, root.dtype
             op.iarg3 = a["src_dtype"]
@@ -865,6 +902,7 @@ _batch_split = 1
 _fuse_upsample = True
 _fuse_followers = True
 _fuse_focus_pair = True
+_fuse_rgb_pool = True
 _head_raw_compute = True
 _split_k = False
 
@@ -874,6 +912,13 @@ def set_focus_pair_fusion(flag):
     launches with the 32-channel half-size map written and read back (ablation / comparison)."""
     global _fuse_focus_pair
     _fuse_focus_pair = bool(flag)
+
+
+def set_rgb_pool_fusion(flag):
+    """Whether plans take a 2x2 / stride 2 max pool that directly follows the 3-channel first layer in that layer's
+    epilogue (default on).  Off: two launches (ablation / comparison)."""
+    global _fuse_rgb_pool
+    _fuse_rgb_pool = bool(flag)
 
 
 def set_split_k(flag):
@@ -1007,7 +1052,7 @@ def _op_info(kind, a):
                     bytes=px * Cc * 2 * 2 + 10 * Cc * Cc * 2, shape=(x.N, x.H, x.W, Cc, Cc, 3, 1))
     if kind == "rgb_conv":
         y, pc = a["y"], a["pc"]
-        return dict(kind="conv", label="conv_rgb3x3", flops=2.0 * y.N * y.H * y.W * pc.Cout * 27,
+        return dict(kind="conv", label="conv_rgb3x3", flops=2.0 * a["N"] * a["H"] * a["W"] * pc.Cout * 27,
                     bytes=a["N"] * 3 * a["H"] * a["W"] * 4 + y.N * y.H * y.W * y.C * esz(y),
                     shape=(a["N"], a["H"], a["W"], 3, pc.Cout, 3, 1))
     if kind == "focus_pair":
@@ -1068,7 +1113,7 @@ class PlanCache:
         # not share one, so the stream is part of the key (callers that pipeline batches over two streams get two plans)
         # the planner switches (fusions on / off, dtype of the raw head maps, batch split) shape the launch list: a
         # plan built under other settings is not reused
-        key = (key, _fuse_upsample, _fuse_followers, _fuse_focus_pair, _head_raw_compute, _batch_split, _split_k)
+        key = (key, _fuse_upsample, _fuse_followers, _fuse_focus_pair, _fuse_rgb_pool, _head_raw_compute, _batch_split, _split_k)
         if torch.cuda.is_available() and torch.cuda.is_initialized():
             key = (key, torch.cuda.current_stream().cuda_stream)
         p = self.plans.get(key)
