@@ -138,6 +138,13 @@ __global__ void spp_kernel(const SliceArgs a) {
 constexpr int kSppMaxHW = 512;
 constexpr int kSppGV = 4;   // channel vectors (16 bytes each) per workgroup
 
+// bf16 planes are kept in LDS as order-preserving 16-bit integers (the low 15 bits of a negative value inverted: the
+// transform is its own inverse), so that a tap is four packed 16-bit integer maxima per 16-byte vector instead of
+// eight unpack / compare / repack sequences: the passes were bound by that arithmetic, not by LDS.  (For finite values
+// the result is fmaxf's; +0 wins over -0.)
+typedef short short8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ short8v bf16_order_keys(short8v v) { return v ^ ((v >> 15) & (short)0x7fff); }
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void spp_lds_kernel(const SliceArgs a) {
     __shared__ __attribute__((aligned(16))) T buf[2][kSppMaxHW * kSppGV * V];
@@ -148,6 +155,43 @@ __global__ __launch_bounds__(256) void spp_lds_kernel(const SliceArgs a) {
     const T* xin = reinterpret_cast<const T*>(a.x) + (size_t)n * hw * a.x_ld + a.x_coff + c;
     T* yout = reinterpret_cast<T*>(a.y) + (size_t)n * hw * a.y_ld + a.y_coff + c;
     const int items = hw * kSppGV;
+    if constexpr (sizeof(T) == 2 && V == 8) {
+        short8v* k0 = reinterpret_cast<short8v*>(&buf[0][0]);
+        short8v* k1 = reinterpret_cast<short8v*>(&buf[1][0]);
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int p = it / kSppGV, v = it - p * kSppGV;
+            k0[it] = bf16_order_keys(*reinterpret_cast<const short8v*>(xin + (size_t)p * a.x_ld + v * V));
+        }
+        __syncthreads();
+        for (int stage = 0; stage < 3; ++stage) {
+            for (int it = threadIdx.x; it < items; it += 256) {          // row pass: k0 -> k1
+                const int p = it / kSppGV, v = it - p * kSppGV;
+                const int h = p / a.W, w = p - h * a.W;
+                short8v m = k0[it];
+#pragma unroll
+                for (int d = -2; d <= 2; ++d) {
+                    if (d == 0) continue;
+                    if ((unsigned)(w + d) < (unsigned)a.W) m = __builtin_elementwise_max(m, k0[it + d * kSppGV]);
+                }
+                k1[it] = m;
+            }
+            __syncthreads();
+            for (int it = threadIdx.x; it < items; it += 256) {          // column pass: k1 -> k0 and this stage's output slice
+                const int p = it / kSppGV, v = it - p * kSppGV;
+                const int h = p / a.W;
+                short8v m = k1[it];
+#pragma unroll
+                for (int d = -2; d <= 2; ++d) {
+                    if (d == 0) continue;
+                    if ((unsigned)(h + d) < (unsigned)a.H) m = __builtin_elementwise_max(m, k1[it + d * a.W * kSppGV]);
+                }
+                k0[it] = m;
+                *reinterpret_cast<short8v*>(yout + (size_t)p * a.y_ld + stage * a.C + v * V) = bf16_order_keys(m);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int it = threadIdx.x; it < items; it += 256) {
         const int p = it / kSppGV, v = it - p * kSppGV;
         vstore<T, V>(&buf[0][it * V], vload<T, V>(xin + (size_t)p * a.x_ld + v * V));
