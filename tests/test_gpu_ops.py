@@ -490,6 +490,9 @@ CONV_CASES = [
     # grids where the dispatcher picks the 128 x 256 eight-wave tile (800 -> 400 workgroups), ragged last tile
     (16, 80, 79, 64, 128, 3, 1, 1, "silu", "after"),
     (16, 80, 80, 128, 250, 1, 1, 0, "none", None),
+    # 1x1, 128 / 256 input channels, at least 65536 pixels: the streaming kernel (bf16); ragged pixel and channel counts
+    (12, 80, 80, 128, 128, 1, 1, 0, "silu", None),
+    (11, 79, 77, 256, 200, 1, 1, 0, "leaky", None),
 ]
 
 
@@ -530,8 +533,37 @@ def test_conv_against_torch(compute, tol, case):
     out = _run_graph(build, *([x, r] if resk else [x]), compute=compute)
     assert out["y"].shape == ref.shape
     assert rel_err(out["y"].float().cpu(), ref) < tol
-    if N == 16:
-        assert engine.conv_kernel_label(Cin, Cout, k, k, p, _ffi.BF16, _ffi.BF16, M=N * Ho * Wo).startswith("conv_dma<128x256")
+    if N == 16 and k == 3:
+        assert engine.conv_kernel_label(Cin, Cout, k, k, p, _ffi.BF16, _ffi.BF16, M=N * Ho * Wo, stride=s,
+                                        res=resk is not None).startswith("conv_dma<128x256")
+    if N in (11, 12):
+        assert engine.conv_kernel_label(Cin, Cout, k, k, p, _ffi.BF16, _ffi.BF16, M=N * Ho * Wo, stride=s).startswith("conv_pw<")
+
+
+@pytest.mark.parametrize("geom", [(30, 48, 48, 128, 128, "silu"), (29, 49, 47, 256, 192, "leaky"), (31, 47, 49, 128, 256, "silu")])
+def test_conv_pw_streaming_equals_tiled(geom):
+    """A 1x1 convolution over at least 65536 pixels goes to the streaming kernel (weights resident in LDS, pixel
+    fragments straight from the map into registers), the same layer over one image to the tiled kernel: same MFMA, same
+    K order, same epilogue -- every image of the batch equals its own single-image run bit for bit."""
+    N, H, W, cin, cout, act = geom
+    gen = _gen(41, f"pw{geom}")
+    x = torch.randn(N, cin, H, W, generator=gen).bfloat16().float()
+    conv = nn.Conv2d(cin, cout, 1).requires_grad_(False)
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / cin) ** 0.5)
+    conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    code = _ffi.ACT_SILU if act == "silu" else _ffi.ACT_LEAKY
+    assert engine.conv_kernel_label(cin, cout, 1, 1, 0, _ffi.BF16, _ffi.BF16, M=N * H * W).startswith("conv_pw<")
+    assert engine.conv_kernel_label(cin, cout, 1, 1, 0, _ffi.BF16, _ffi.BF16, M=H * W).startswith("conv_dma<")
+
+    def build(gr, ins):
+        gr.to_nchw(gr.conv(ins[0], conv, act=code, slope=0.1), "y")
+
+    full = _run_graph(build, x, compute="bf16")["y"].float().cpu()
+    ref = F.silu(conv(x)) if act == "silu" else F.leaky_relu(conv(x), 0.1)
+    assert rel_err(full.numpy(), ref.numpy()) < 2e-2
+    for n in (0, N // 2, N - 1):
+        one = _run_graph(build, x[n:n + 1], compute="bf16")["y"].float().cpu()
+        assert torch.equal(one[0], full[n]), f"image {n}"
 
 
 GROUPED_CASES = [

@@ -63,6 +63,8 @@ def main():
                     "layer before left in the caches, not from eight runs of itself")
     ap.add_argument("--tiles", nargs="*", default=[], help="YDET_CONV_TILE per library ('-' for none): each library reads "
                     "the variable once, at its first launch, so copies of one build can run different forced tiles")
+    ap.add_argument("--pw", nargs="*", default=[], help="YDET_PW per library ('-' for none; read once per library, as above): "
+                    "0 keeps the 1x1 layers away from the streaming kernel of conv_pw.hip")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -106,6 +108,10 @@ def main():
                 os.environ["YDET_CONV_TILE"] = tile
             else:
                 os.environ.pop("YDET_CONV_TILE", None)
+            pw = args.pw[li] if li < len(args.pw) else "-"
+            os.environ.pop("YDET_PW", None)
+            if pw != "-":
+                os.environ["YDET_PW"] = pw
             if h.ydet_conv2d_nhwc(ds[li], stream) != 0:
                 raise RuntimeError(f"{name}: {h.ydet_last_error().decode()}")
         torch.cuda.synchronize()

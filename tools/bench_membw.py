@@ -19,3 +19,9 @@ for name, fn, nb in (("copy", lambda: y.copy_(x), 8 * n), ("sigmoid", lambda: to
                      ("fill", lambda: y.fill_(1.0), 4 * n), ("sum", lambda: x.sum(), 4 * n)):
     t = timeit(fn)
     print(f"{name}: {t:.0f} us  {nb / t / 1e6:.2f} TB/s")
+
+# the size of one 80x80x128-channel bf16 map at batch 64 (a layer's input is what the layer before just wrote)
+m = 64 * 80 * 80 * 128 // 2
+xs, ys = x[:m], y[:m]
+t = timeit(lambda: ys.copy_(xs), 50)
+print(f"copy 105 MB -> 105 MB: {t:.1f} us  {8 * m / t / 1e6:.2f} TB/s")

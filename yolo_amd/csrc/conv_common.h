@@ -173,5 +173,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 bool conv_big_takes(const ConvArgs& a);
 int launch_conv_big(const ConvArgs& a, hipStream_t stream);
 
+// The streaming 1x1 kernel of conv_pw.hip (bf16 -> bf16, 128 or 256 input channels, many pixels; bit-identical to the
+// tiled kernel): whether it takes the launch, and the launch itself.
+bool conv_pw_takes(const ConvArgs& a);
+int launch_conv_pw(const ConvArgs& a, hipStream_t stream);
+
 }  // namespace conv
 }  // namespace ydet

@@ -14,6 +14,7 @@ Layout decisions
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -991,11 +992,15 @@ def _wide_tile_pays(M, cout, K):
     return r256 * (0.85 if K >= 256 else 1.0) < r128 - 0.02
 
 
-def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=True):
+def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=True, stride=1, res=False):
     """Name of the kernel instantiation ydet_conv2d_nhwc launches for this shape (mirrors launch_dtype() / launch_tile()
-    in csrc/conv.hip), so that timings keyed by it line up with a profiler's per-symbol statistics."""
+    in csrc/conv.hip and conv_pw_takes() in csrc/conv_pw.hip), so that timings keyed by it line up with a profiler's
+    per-symbol statistics."""
     if not plain:
         return "conv_direct"
+    if (kh == 1 and kw == 1 and pad == 0 and stride == 1 and not res and in_dt == _ffi.BF16 and out_dt == _ffi.BF16
+            and cin_phys in (128, 256) and cout > 64 and M >= 65536 and os.environ.get("YDET_PW", "1")[:1] != "0"):
+        return f"conv_pw<k{cin_phys}>"
     bn, bm = conv_tile(cout)
     bk = 32 if in_dt == _ffi.BF16 else 16
     dts = f"{'bf16' if in_dt == _ffi.BF16 else 'f32'}->{'bf16' if out_dt == _ffi.BF16 else 'f32'}"
@@ -1035,7 +1040,7 @@ def _op_info(kind, a):
         if a.get("up") is not None:     # the first C_up channels come from a map of a quarter of the pixels
             nbytes -= x.N * x.H * x.W * a["up"][1] * esz(x) * 3 // 4
         return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W,
-                                                         plain=pc.plain),
+                                                         plain=pc.plain, stride=a["stride"], res=a["res"] is not None),
                     flops=flops,
                     bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
