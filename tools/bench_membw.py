@@ -25,3 +25,17 @@ m = 64 * 80 * 80 * 128 // 2
 xs, ys = x[:m], y[:m]
 t = timeit(lambda: ys.copy_(xs), 50)
 print(f"copy 105 MB -> 105 MB: {t:.1f} us  {8 * m / t / 1e6:.2f} TB/s")
+
+# ping-pong: every copy reads what the copy before it wrote (does written data stay in the memory-side cache?)
+a, b = x[:m], y[:m]
+def pingpong():
+    b.copy_(a); a.copy_(b)
+t = timeit(pingpong, 25) / 2
+print(f"ping-pong copy 105 MB <-> 105 MB: {t:.1f} us per copy  {8 * m / t / 1e6:.2f} TB/s")
+# a chain over four buffers (420 MB working set): each copy reads the buffer written by the one before
+bufs = [torch.empty(m, device=dev) for _ in range(4)]
+def chain():
+    for i in range(4):
+        bufs[(i + 1) % 4].copy_(bufs[i])
+t = timeit(chain, 15) / 4
+print(f"chain of copies over 4 x 105 MB: {t:.1f} us per copy  {8 * m / t / 1e6:.2f} TB/s")

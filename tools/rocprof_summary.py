@@ -18,6 +18,9 @@ import sys
 
 
 def label_of(name):
+    m = re.search(r"conv_pw_kernel(?:ILi|<)(\d+)", name)      # first template argument: K steps of 32 channels
+    if m:
+        return f"conv_pw<k{32 * int(m.group(1))}>"
     m = re.search(r"conv_(dma|generic)_kernel", name)
     if m:
         kind = m.group(1)
