@@ -5,14 +5,19 @@
 // tensor of the whole network (written once, read once).  Here it exists only as a 17 x 33 pixel patch in LDS.
 //
 // A workgroup (4 waves) produces an 8 x 16 patch of the second convolution's output pixels:
-//   P0  the 38 x 70 x 3 image patch underneath -> LDS focus tile F[19][35] (12 channels + 4 zeros, bf16, 48-byte pitch)
+//   P0  the 38 x 70 x 3 image patch underneath -> LDS focus tile F[19][35] (12 channels + 4 zeros, bf16, 32-byte pitch)
 //   P1  first convolution on the 17 x 33 patch A of ITS output pixels the second one needs (36 MFMA pixel groups of 16,
 //       K = 9 taps x 16 channels), bias + activation, bf16; pixels outside the map are the second convolution's zero padding
-//       -> LDS A (over F), even and odd columns apart so that a stride-2 tap reads 16 consecutive pixels (80-byte pitch)
+//       -> LDS A (over F), even and odd columns apart so that a stride-2 tap reads 16 consecutive pixels (64-byte slots)
 //   P2  second convolution (K = 9 taps x 32 channels) from A; waves split 2 (channels) x 2 (rows)
-//   P3  optional 1x1 follower: the finished 128 x 64 tile goes through LDS (144-byte pitch) once more
-// Every LDS pitch is an odd number of 16-byte chunks: sixteen consecutive pixels at one channel offset fall on sixteen
-// different bank groups without any swizzle, and every tap offset is an immediate.
+//   P3  optional 1x1 follower: the finished 128 x 64 tile goes through LDS (128-byte slots) once more
+// LDS banking: a ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), i.e. half of
+// a group reads 16-byte chunk c of eight pixels and the other half chunk c + 1 of the eight pixels in between (pixel =
+// lane & 15, chunk = lane >> 4).  An odd pitch in chunks -- 3, 5, 9: what sixteen CONSECUTIVE lanes would want -- makes
+// every such read a two-way conflict (the counters showed half of this kernel's LDS cycles as conflicts).  Conflict-free
+// for any start pixel: a pitch of 2 chunks as it is (F); unpadded 4- and 8-chunk slots with the chunk index XORed with
+// (slot >> 1) & 3 (A) or slot & 7 (T).  Row strides of A are multiples of 8 slots, so the XOR term of a tap depends only
+// on the lane and on whether the tap is the third of its row: two per-lane bases, every other tap offset an immediate.
 //
 // RGB variant (the Darknet-style trunks of the v3 / v4 detectors, models/basemodel/d19.py:83-123 and :215-265, whose first
 // two layers are Conv(3, 32, 3, p=1) and Conv(32, 64, 3, p=1, s=2)): no slicing, F holds the 19 x 35 image pixels
@@ -30,15 +35,16 @@ constexpr int T_H = 8, T_W = 16;                  // output pixels of the second
 constexpr int A_H = 2 * T_H + 1, A_W = 2 * T_W + 1;   // first-convolution pixels underneath (3x3, stride 2, pad 1)
 constexpr int A_N = A_H * A_W;                    // 561
 constexpr int A_FRAGS = (A_N + 15) / 16;          // 36 pixel groups
-constexpr int A_HALF = (A_W + 1) / 2;             // 17 even columns (then 16 odd ones) per row
-constexpr int A_ROW = 2 * A_HALF;                 // 34 pixel slots per row
-constexpr int A_PITCH = 80;                       // bytes per pixel slot (32 channels + 16)
+constexpr int A_HALF = 24;                        // 17 even columns, then (from slot 24) 16 odd ones per row
+constexpr int A_ROW = 40;                         // pixel slots per row; both multiples of 8 (see the XOR term above)
+constexpr int A_PITCH = 64;                       // bytes per pixel slot: 32 channels, chunk index XOR (slot >> 1) & 3
 constexpr int F_H = A_H + 2, F_W = A_W + 2;       // focus pixels underneath (3x3, stride 1, pad 1)
 constexpr int F_N = F_H * F_W;                    // 665
-constexpr int F_PITCH = 48;                       // 16 channels + 16 bytes
-constexpr int T_PITCH = 144;                      // 64 channels + 16 bytes
+constexpr int F_PITCH = 32;                       // 16 channels, no padding
+constexpr int T_PITCH = 128;                      // 64 channels, chunk index XOR slot & 7
 constexpr int KSTEPS0 = 5;                        // first convolution: 9 taps x 16 channels = 144 -> 160
-constexpr int LDS_BYTES = A_H * A_ROW * A_PITCH;  // 46240 >= F (31920), >= T (18432)
+constexpr int LDS_BYTES = A_H * A_ROW * A_PITCH;  // 43520 (three workgroups per CU) >= F (21280), >= T (16384)
+static_assert(A_HALF % 8 == 0 && A_ROW % 8 == 0 && A_HALF >= (A_W + 1) / 2 && A_ROW >= A_HALF + A_W / 2, "A row layout");
 static_assert(LDS_BYTES >= F_N * F_PITCH && LDS_BYTES >= T_H * T_W * T_PITCH, "the three tiles share one LDS region");
 static_assert(A_FRAGS % 4 == 0, "pixel groups split evenly over four waves");
 
@@ -264,7 +270,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int r = p / A_W, c = p - r * A_W;
         bf16x8 o = finish8<SILU0>(acc0[t][0], acc0[t][1], b0lo, b0hi, a.slope0);
         if (!interior1 && !((unsigned)(ar0 + r) < (unsigned)a.H1 && (unsigned)(ac0 + c) < (unsigned)a.W1)) o = bf16x8{};
-        if (p < A_N) *reinterpret_cast<bf16x8*>(lds + (r * A_ROW + (c & 1) * A_HALF + (c >> 1)) * A_PITCH + g * 16) = o;
+        const int slot = r * A_ROW + (c & 1) * A_HALF + (c >> 1);
+        if (p < A_N) *reinterpret_cast<bf16x8*>(lds + slot * A_PITCH + ((g ^ ((slot >> 1) & 3)) << 4)) = o;
     }
     __syncthreads();
 
@@ -275,14 +282,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* abase = lds + ((2 * 4 * wm) * A_ROW + p16) * A_PITCH + g * 16;
+    // (per-lane bases for taps kw = 0, 1 and for kw = 2, which sits one slot further on: the XOR term differs)
+    const char* abase0 = lds + ((2 * 4 * wm) * A_ROW + p16) * A_PITCH + ((g ^ ((p16 >> 1) & 3)) << 4);
+    const char* abase1 = lds + ((2 * 4 * wm) * A_ROW + p16 + 1) * A_PITCH + ((g ^ (((p16 + 1) >> 1) & 3)) << 4);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int kh = t / 3, kw = t - kh * 3;
         bf16x8 xf[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            xf[j] = *reinterpret_cast<const bf16x8*>(abase + ((2 * j + kh) * A_ROW + (kw & 1) * A_HALF + (kw >> 1)) * A_PITCH);
+            xf[j] = *reinterpret_cast<const bf16x8*>((kw >> 1 ? abase1 : abase0) + ((2 * j + kh) * A_ROW + (kw & 1) * A_HALF) * A_PITCH);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __syncthreads();     // every wave is done reading A
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<bf16x8*>(lds + ((4 * wm + j) * 16 + p16) * T_PITCH + co * 2) =
+            *reinterpret_cast<bf16x8*>(lds + ((4 * wm + j) * 16 + p16) * T_PITCH + (((co >> 3) ^ (p16 & 7)) << 4)) =
                 finish8<SILU1>(acc1[0][j], acc1[1][j], b1lo, b1hi, a.slope1);
         __syncthreads();
         f32x4 acc2[2][4];
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             bf16x8 xf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                xf[j] = *reinterpret_cast<const bf16x8*>(lds + ((4 * wm + j) * 16 + p16) * T_PITCH + (32 * s + 8 * g) * 2);
+                xf[j] = *reinterpret_cast<const bf16x8*>(lds + ((4 * wm + j) * 16 + p16) * T_PITCH + (((4 * s + g) ^ (p16 & 7)) << 4));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
