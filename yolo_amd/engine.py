@@ -15,6 +15,7 @@ Layout decisions
 import ctypes as C
 import math
 import os
+import threading
 
 import torch
 
@@ -676,6 +677,9 @@ class Plan:
                     if nb > 0:
                         op.conv.splitk_ws, op.conv.splitk_ws_bytes = ws.data_ptr(), ws.numel()
         self.ops = self.op_lists[0]
+        # run() writes the caller's pointers into the shared launch records and then enqueues them: one host thread at a
+        # time per plan (the enqueue copies the records into kernel arguments, so the lock ends with the call)
+        self._run_lock = threading.Lock()
         self._lists = (C.POINTER(_ffi.Op) * replicas)(*[C.cast(o, C.POINTER(_ffi.Op)) for o in self.op_lists])
         self._counts = (C.c_int * replicas)(*([n] * replicas))
 
@@ -823,6 +827,10 @@ class Plan:
         """xs: the NCHW CUDA inputs (fp32 or bf16; other dtypes are converted to fp32), in the order
         they were declared.  Returns {name: tensor} of the plan's outputs.  `timer` (a ydet_timer handle, plans with
         one replica only): record an event before the first and after every op into marks first_mark.."""
+        with self._run_lock:
+            return self._run_locked(xs, timer, first_mark)
+
+    def _run_locked(self, xs, timer, first_mark):
         lib = _ffi.lib()
         R = self.R
         assert len(xs) == len(self.patch_in), f"plan takes {len(self.patch_in)} inputs"
