@@ -1013,7 +1013,12 @@ def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=Tru
     bk = 32 if in_dt == _ffi.BF16 else 16
     dts = f"{'bf16' if in_dt == _ffi.BF16 else 'f32'}->{'bf16' if out_dt == _ffi.BF16 else 'f32'}"
     dma = cin_phys % bk == 0 and kh * kw <= 32
-    if bn == 128 and dma and out_dt == _ffi.BF16 and _wide_tile_pays(M, cout, kh * kw * cin_phys):
+    K = kh * kw * cin_phys
+    tiles = (M + 127) // 128 * ((cout + 127) // 128)
+    # few tiles and a long K: the 128-byte-row variants of the 128 x 128 tile (same symbol family, same label)
+    k8 = (bn == 128 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16 and cin_phys % 64 == 0 and kh * kw <= 32 and K >= 256
+          and (tiles <= 512 or (tiles <= 1024 and K >= 2048)) and os.environ.get("YDET_CONV_K8", "1") != "0")
+    if bn == 128 and dma and out_dt == _ffi.BF16 and not k8 and _wide_tile_pays(M, cout, K):
         bm = 256
     if bn >= 64 and dma:
         return f"conv_dma<{bn}x{bm},{dts}>"
