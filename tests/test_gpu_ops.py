@@ -1132,7 +1132,9 @@ def test_voc_metric_on_device_golden(golden):
 
 # ---- nearest upsample + concat folded into the 1x1 convolution that reads them ---------------------------------------
 @pytest.mark.parametrize("compute", ["bf16", "fp32"])
-@pytest.mark.parametrize("shape", [(2, 64, 128, 10, 12, 128), (3, 128, 64, 20, 20, 256), (1, 256, 256, 7, 9, 64)])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 10, 12, 128), (3, 128, 64, 20, 20, 256), (1, 256, 256, 7, 9, 64),
+                                   # at least 65536 pixels and 128 / 256 channels in all: the streaming 1x1 kernel (bf16)
+                                   (12, 128, 128, 40, 40, 128), (11, 64, 64, 39, 41, 200)])
 def test_conv_reads_upsampled_source(compute, shape):
     """cat(upsample(a), b) -> 1x1 conv with the upsample never materialised equals the three separate ops bit for bit
     (same operands, same accumulation order), and matches torch."""
