@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-vendor", action="store_true", help="skip the vendor-GEMM reference of the dominant kernel's launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the other configurations (YOLOv3-tiny 416 bs1 with its CPU leg, YOLOv2-D19 416 bs32, YOLOv3-SPP "
@@ -305,6 +306,9 @@ def main():
         "kernels": kernels,
     }
 
+    if rank == 0 and world == 1 and not args.no_vendor:
+        result["roofline"]["vendor_gemm"] = vendor_gemm(dev, [i for i in plan.op_info if i["label"] == dom_label],
+                                                        dom["ms"] / n_ev)
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(model, args)
     if rank == 0 and world == 1 and not args.no_configs:
@@ -315,6 +319,41 @@ def main():
         print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def vendor_gemm(dev, infos, ours_ms):
+    """The launches of the dominant kernel as PLAIN bf16 GEMMs of the same M x N x K (M pixels, N output channels,
+    K = taps x input channels; no gather, bias, activation or residual) through torch.matmul, i.e. hipBLASLt / rocBLAS on
+    this box: a reference point for `achieved` besides the dense peak.  Outside the timed region."""
+    import torch
+    shapes = {}
+    for i in infos:
+        n, h, w, cin, cout, k, s = i["shape"]
+        key = (n * (h // s) * (w // s), cout, k * k * cin)
+        shapes[key] = shapes.get(key, 0) + 1
+    tot_us, tot_flop = 0.0, 0.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for (M, N, K), cnt in shapes.items():
+        a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+        for _ in range(5):
+            a @ b.t()
+        ts = []
+        for _ in range(5):
+            e0.record()
+            for _ in range(8):
+                a @ b.t()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) / 8 * 1e3)
+        us = sorted(ts)[2]
+        tot_us += cnt * us
+        tot_flop += cnt * 2.0 * M * N * K
+        del a, b
+    return {"tflops": round(tot_flop / tot_us / 1e6, 1), "us_per_step": round(tot_us, 1), "ours_us_per_step": round(ours_ms * 1e3, 1),
+            "launches": sum(shapes.values()),
+            "note": "the same launches as plain bf16 GEMMs (M pixels x N channels x K) through torch.matmul = the vendor "
+                    "library on this box, bursts of eight, median; no gather / bias / activation / residual"}
 
 
 def cpu_baseline(model, args):
