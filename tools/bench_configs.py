@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the other benchmark configurations (forward + decode + per-class NMS of every image), one JSON line
 each: YOLOv2-D19 416 bs32, YOLOv3-SPP 608 bs64, YOLOv4-CSPDarknet53 608 bs64, YOLOv3-tiny 416 bs1 / bs64.
-The headline YOLOv5s line is bench.py's; this tool only adds the figures DESIGN.md quotes for the other models.
+The headline YOLOv5s line is bench.py's; this tool only adds the figures of the other models.
 
     python tools/bench_configs.py [--steps 20] [--compute bf16]
 """
