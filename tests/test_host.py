@@ -418,3 +418,30 @@ def test_v5s_fuse_and_augment_torch_face_match_golden(golden):
         m._lower(gr, 2, 3, 96, 128)
         kinds = [k for k, _ in gr.finalize().g.ops]
         assert kinds.count("head_decode") == 3 and (comp == "fp32" or kinds.count("c3tail") == 1)
+
+
+def test_kernel_labels_mirror_the_dispatcher(monkeypatch):
+    """engine.conv_kernel_label names the kernel the library picks for a shape (the benchmark groups its per-op times by
+    it): streaming 1x1 kernel for 128 / 256 input channels over at least 65536 pixels (bf16, no residual, stride 1),
+    128-byte-row form of the 128 x 128 tile for few tiles and a long K, wide tile where the grid fits, else 128 x 128."""
+    from yolo_amd import _ffi, engine
+    B, F = _ffi.BF16, _ffi.F32
+    lab = engine.conv_kernel_label
+    monkeypatch.delenv("YDET_PW", raising=False)
+    monkeypatch.delenv("YDET_CONV_K8", raising=False)
+    assert lab(128, 128, 1, 1, 0, B, B, M=409600) == "conv_pw<k128>"
+    assert lab(256, 256, 1, 1, 0, B, B, M=102400) == "conv_pw<k256>"
+    assert lab(256, 256, 1, 1, 0, B, B, M=25600).startswith("conv_dma<")          # too few pixels
+    assert lab(128, 128, 1, 1, 0, B, B, M=409600, res=True).startswith("conv_dma<")
+    assert lab(128, 128, 1, 1, 0, B, B, M=409600, stride=2).startswith("conv_dma<")
+    assert lab(128, 64, 1, 1, 0, B, B, M=409600).startswith("conv_dma<64x128")     # narrow outputs keep their tile
+    assert lab(128, 128, 1, 1, 0, F, F, M=409600).startswith("conv_dma<")          # fp32 plans
+    assert lab(512, 256, 1, 1, 0, B, B, M=102400).startswith("conv_dma<")          # 512 input channels
+    monkeypatch.setenv("YDET_PW", "0")
+    assert lab(128, 128, 1, 1, 0, B, B, M=409600).startswith("conv_dma<")
+    monkeypatch.delenv("YDET_PW")
+    # 3x3, 256 -> 512, stride 2 at 40x40 (25600 output pixels): 800 tiles of 128 x 128 and K = 2304 -> 128-byte rows
+    assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<128x128,bf16->bf16>"
+    assert lab(128, 128, 3, 3, 1, B, B, M=102400, res=True) == "conv_dma<128x256,bf16->bf16>"
+    monkeypatch.setenv("YDET_CONV_K8", "0")
+    assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<128x256,bf16->bf16>"
