@@ -307,8 +307,11 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_vendor:
-        result["roofline"]["vendor_gemm"] = vendor_gemm(dev, [i for i in plan.op_info if i["label"] == dom_label],
-                                                        dom["ms"] / n_ev)
+        try:     # (a reference point only: never in the way of the result line)
+            result["roofline"]["vendor_gemm"] = vendor_gemm(dev, [i for i in plan.op_info if i["label"] == dom_label],
+                                                            dom["ms"] / n_ev)
+        except Exception as exc:      # noqa: BLE001
+            result["roofline"]["vendor_gemm"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     if rank == 0 and world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(model, args)
     if rank == 0 and world == 1 and not args.no_configs:
