@@ -566,6 +566,37 @@ def test_conv_pw_streaming_equals_tiled(geom):
         assert torch.equal(one[0], full[n]), f"image {n}"
 
 
+@pytest.mark.parametrize("geom", [(32, 40, 40, 128, 512, 3, 1, True), (31, 41, 39, 64, 400, 3, 1, False), (30, 44, 44, 512, 256, 1, 1, False)])
+def test_conv_256_tile_equals_small_launch(geom):
+    """Wide layers with a long K and about a tile per CU take the 256 x 256 sixteen-wave tile; one image of the same layer
+    takes a 128-wide tile.  Same MFMA, same K order, same epilogue: every image equals its own single-image run bit for
+    bit (ragged channel tile: 400 = 256 + 144; ragged pixel tiles; residual)."""
+    N, H, W, cin, cout, k, s, res = geom
+    gen = _gen(43, f"t256{geom}")
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(N, cin, H, W, generator=gen).bfloat16().float()
+    r = torch.randn(N, cout, Ho, Wo, generator=gen).bfloat16().float() if res else None
+    conv = nn.Conv2d(cin, cout, k, s, p).requires_grad_(False)
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (cin * k * k)) ** 0.5)
+    conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    assert engine.conv_kernel_label(cin, cout, k, k, p, _ffi.BF16, _ffi.BF16, M=N * Ho * Wo, stride=s,
+                                    res=res).startswith("conv_dma<256x256")
+    assert not engine.conv_kernel_label(cin, cout, k, k, p, _ffi.BF16, _ffi.BF16, M=Ho * Wo, stride=s,
+                                        res=res).startswith("conv_dma<256x256")
+
+    def build(gr, ins):
+        kw = dict(res=ins[1], res_mode=_ffi.RES_AFTER_ACT) if res else {}
+        gr.to_nchw(gr.conv(ins[0], conv, act=_ffi.ACT_SILU, **kw), "y")
+
+    full = _run_graph(build, *([x, r] if res else [x]), compute="bf16")["y"].float().cpu()
+    ref = F.silu(conv(x)) + (r if res else 0)
+    assert rel_err(full.numpy(), ref.numpy()) < 2e-2
+    for n in (0, N // 2, N - 1):
+        one = _run_graph(build, *([x[n:n + 1], r[n:n + 1]] if res else [x[n:n + 1]]), compute="bf16")["y"].float().cpu()
+        assert torch.equal(one[0], full[n]), f"image {n}"
+
+
 GROUPED_CASES = [
     # N, H, W, Cin, Cout, k, s, p, groups, dilation, act, residual
     (2, 20, 20, 64, 64, 3, 1, 1, 64, 1, "silu", None),       # depthwise (DWConv, yolov5_official/modules.py:19-21)

@@ -423,7 +423,8 @@ def test_v5s_fuse_and_augment_torch_face_match_golden(golden):
 def test_kernel_labels_mirror_the_dispatcher(monkeypatch):
     """engine.conv_kernel_label names the kernel the library picks for a shape (the benchmark groups its per-op times by
     it): streaming 1x1 kernel for 128 / 256 input channels over at least 65536 pixels (bf16, no residual, stride 1),
-    128-byte-row form of the 128 x 128 tile for few tiles and a long K, wide tile where the grid fits, else 128 x 128."""
+    256 x 256 tile for wide layers with a long K and about a tile per CU, 128-byte-row form of the 128 x 128 tile for few
+    tiles and a long K, wide tile where the grid fits, else 128 x 128."""
     from yolo_amd import _ffi, engine
     B, F = _ffi.BF16, _ffi.F32
     lab = engine.conv_kernel_label
@@ -440,8 +441,13 @@ def test_kernel_labels_mirror_the_dispatcher(monkeypatch):
     monkeypatch.setenv("YDET_PW", "0")
     assert lab(128, 128, 1, 1, 0, B, B, M=409600).startswith("conv_dma<")
     monkeypatch.delenv("YDET_PW")
-    # 3x3, 256 -> 512, stride 2 at 40x40 (25600 output pixels): 800 tiles of 128 x 128 and K = 2304 -> 128-byte rows
-    assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<128x128,bf16->bf16>"
+    # 3x3, 256 -> 512, stride 2 at 40x40 (25600 output pixels, K = 2304): 200 tiles of 256 x 256 -> the sixteen-wave tile;
+    # without it 800 tiles of 128 x 128 and a long K -> 128-byte rows; without either the wide tile
+    monkeypatch.delenv("YDET_CONV_256", raising=False)
+    assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<256x256,bf16->bf16>"
+    assert lab(256, 256, 3, 3, 1, B, B, M=25600, res=True) == "conv_dma<128x128,bf16->bf16>"      # 100 tiles: too few
     assert lab(128, 128, 3, 3, 1, B, B, M=102400, res=True) == "conv_dma<128x256,bf16->bf16>"
+    monkeypatch.setenv("YDET_CONV_256", "0")
+    assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<128x128,bf16->bf16>"
     monkeypatch.setenv("YDET_CONV_K8", "0")
     assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<128x256,bf16->bf16>"

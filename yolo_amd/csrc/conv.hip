@@ -1026,6 +1026,18 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
     if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
     if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
+        // Wide layers (256 output channels and more) with K >= 512 and enough pixels for about one tile per CU: the
+        // 256 x 256 tile with sixteen waves (one workgroup per CU) moves a third fewer bytes through the LDS-DMA path per
+        // FLOP than two 128 x 256 workgroups.  Measured on MI355X, isolated and bit-identical: 3x3 256 -> 512 at 38 x 38
+        // 222 -> 204 us, 3x3 512 -> 1024 at 19 x 19 251 -> 235 us, 3x3 / 2 128 -> 256 at 80 x 80 78.5 -> 75.0 us, level
+        // on the 20 x 20 1x1 layers; with one channel tile and 100 pixel tiles (a 3x3 256 -> 256 at 20 x 20) it leaves
+        // most of the chip idle (37 -> 63 us).  YDET_CONV_256=0 turns the rule off.
+        static const bool t256_on = !(getenv("YDET_CONV_256") && atoi(getenv("YDET_CONV_256")) == 0);
+        const int rem256 = a.Cout % 256;
+        const long long tiles256 = (a.M + 255) / 256 * ((a.Cout + 255) / 256);
+        if (t256_on && a.Cout >= 256 && (rem256 == 0 || rem256 > 128) && a.Cin % 32 == 0 && a.KH * a.KW <= 32 &&
+            a.KH * a.KW * a.Cin >= 512 && tiles256 >= 192 && a.splits <= 1)
+            return launch_tile<TIN, TOUT, 256, 256, 4, 4>(a, stream);
         // Few tiles and a long K: the launch is one or two rounds of workgroups whose time is the K loop's, and the
         // 128-byte-row variant walks K in half as many steps (half the barriers and waits; two stages of twice the
         // size).  With many tiles per CU the three-stage ring at three workgroups per CU hides more (measured).

@@ -1018,6 +1018,11 @@ def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=Tru
     # few tiles and a long K: the 128-byte-row variants of the 128 x 128 tile (same symbol family, same label)
     k8 = (bn == 128 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16 and cin_phys % 64 == 0 and kh * kw <= 32 and K >= 256
           and (tiles <= 512 or (tiles <= 1024 and K >= 2048)) and os.environ.get("YDET_CONV_K8", "1") != "0")
+    rem256 = cout % 256
+    if (bn == 128 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16 and cout >= 256 and (rem256 == 0 or rem256 > 128)
+            and cin_phys % 32 == 0 and kh * kw <= 32 and K >= 512 and (M + 255) // 256 * ((cout + 255) // 256) >= 192
+            and os.environ.get("YDET_CONV_256", "1") != "0"):
+        return f"conv_dma<256x256,{dts}>"
     if bn == 128 and dma and out_dt == _ffi.BF16 and not k8 and _wide_tile_pays(M, cout, K):
         bm = 256
     if bn >= 64 and dma:
