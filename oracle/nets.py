@@ -3,10 +3,40 @@
 networks are re-derived from the reference's constructors / forward() bodies and read their weights by
 state_dict key, so a key or wiring mistake in the product cannot cancel out.
 """
+import contextlib
 import math
 
 import torch
 import torch.nn.functional as F
+
+# ---- bf16 storage floor ------------------------------------------------------------------------------
+# Inside `with bf16_storage():` the networks below run as a layer-by-layer bf16 inference pipeline stores them: BatchNorm
+# is folded into the convolution weights (w * gamma / sqrt(var + eps), the rest a fp32 bias), the folded weights are
+# rounded to bf16, and every tensor a layer hands to the next one (a convolution's activated output, a residual sum, an
+# interpolated map) is rounded to bf16 once; sums, BatchNorm shifts and activations are computed in fp32 and the
+# prediction maps stay fp32.  The distance of these head maps from the plain fp32 ones is what ANY implementation with
+# bf16 weights and activations loses on that network and input -- the floor the bf16 GPU path is measured against.
+# (Which weights get rounded matters: rounding the raw weights instead of the folded ones moves YOLOv5s's 640 x 640 head
+# maps from 1.3-1.7 % to 2.3-3.2 % relative L2, the error being dominated by a few coherent directions.)
+_BF16 = False
+
+
+@contextlib.contextmanager
+def bf16_storage():
+    global _BF16
+    old, _BF16 = _BF16, True
+    try:
+        yield
+    finally:
+        _BF16 = old
+
+
+def _q(t):
+    return t.bfloat16().float() if _BF16 else t
+
+
+def _conv2d(x, w, b=None, **kw):
+    return F.conv2d(_q(x), _q(w), b, **kw)
 
 
 # ---- building blocks -------------------------------------------------------------------------------
@@ -15,24 +45,36 @@ def _bn(x, sd, p, eps):
                         False, 0.0, eps)
 
 
-def conv_a(x, sd, p, s=1, act=True):
-    """utils/moduleUtils.py:8-24: Conv2d(bias) + BN(eps 1e-5) + LeakyReLU(0.1); padding 1 for 3x3, 0 for 1x1."""
+def _conv_bn(x, w, b, sd, bn, eps, **kw):
+    """BatchNorm(conv(x) + b); with bf16 storage: the folded form, folded weights and input rounded to bf16."""
+    if not _BF16:
+        return _bn(F.conv2d(x, w, b, **kw), sd, bn, eps)
+    scale = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + eps)
+    shift = sd[bn + ".bias"] - sd[bn + ".running_mean"] * scale
+    if b is not None:
+        shift = shift + b * scale
+    return F.conv2d(_q(x), _q(w * scale.view(-1, 1, 1, 1)), shift, **kw)
+
+
+def conv_a(x, sd, p, s=1, act=True, store=True):
+    """utils/moduleUtils.py:8-24: Conv2d(bias) + BN(eps 1e-5) + LeakyReLU(0.1); padding 1 for 3x3, 0 for 1x1.
+    store=False: the caller adds something before the tensor is handed on (no bf16 rounding here)."""
     w = sd[p + ".conv.0.weight"]
-    y = F.conv2d(x, w, sd[p + ".conv.0.bias"], stride=s, padding=w.shape[-1] // 2)
-    y = _bn(y, sd, p + ".conv.1", 1e-5)
-    return F.leaky_relu(y, 0.1) if act else y
+    y = _conv_bn(x, w, sd[p + ".conv.0.bias"], sd, p + ".conv.1", 1e-5, stride=s, padding=w.shape[-1] // 2)
+    y = F.leaky_relu(y, 0.1) if act else y
+    return _q(y) if store else y
 
 
-def conv_b(x, sd, p, s=1, act="silu", eps=1e-3):
+def conv_b(x, sd, p, s=1, act="silu", eps=1e-3, store=True):
     """yolov5_official/modules.py:24-41: Conv2d(no bias, autopad) + BN(eps 1e-3 after initialize_weights) + SiLU;
     models/common.py:22-37 uses LeakyReLU(0.01) instead."""
     w = sd[p + ".conv.weight"]
-    y = _bn(F.conv2d(x, w, None, stride=s, padding=w.shape[-1] // 2), sd, p + ".bn", eps)
+    y = _conv_bn(x, w, None, sd, p + ".bn", eps, stride=s, padding=w.shape[-1] // 2)
     if act == "silu":
-        return F.silu(y)
-    if act == "leaky001":
-        return F.leaky_relu(y, 0.01)
-    return y
+        y = F.silu(y)
+    elif act == "leaky001":
+        y = F.leaky_relu(y, 0.01)
+    return _q(y) if store else y
 
 
 def spp_cat(x):
@@ -42,8 +84,8 @@ def spp_cat(x):
 
 # ---- YOLOv5s (yolov5_official/model.py:88-265 + yamls/yolov5s.yaml) -----------------------------------
 def _bottleneck_b(x, sd, p, add, act):
-    y = conv_b(conv_b(x, sd, p + ".cv1", act=act), sd, p + ".cv2", act=act)
-    return x + y if add else y                                                        # modules.py:218
+    y = conv_b(conv_b(x, sd, p + ".cv1", act=act), sd, p + ".cv2", act=act, store=not add)
+    return _q(x + y) if add else y                                                        # modules.py:218
 
 
 def _c3(x, sd, p, n, shortcut, act):
@@ -79,7 +121,7 @@ def yolov5_heads(sd, x, cfg, act="silu"):
         elif m == "Concat":
             x = torch.cat(inp, 1)
         elif m == "Detect":
-            return [F.conv2d(t, sd[f"{p}.m.{k}.weight"], sd[f"{p}.m.{k}.bias"]) for k, t in enumerate(inp)]
+            return [_conv2d(t, sd[f"{p}.m.{k}.weight"], sd[f"{p}.m.{k}.bias"]) for k, t in enumerate(inp)]
         else:
             raise NotImplementedError(m)
         outs.append(x)
@@ -107,7 +149,7 @@ def dark19(sd, x, p="base"):                                                    
 
 def _resblock(x, sd, p, n):                                                           # moduleUtils.py:45-59
     for i in range(n):
-        x = conv_a(conv_a(x, sd, f"{p}.module_list.{i}.0"), sd, f"{p}.module_list.{i}.1") + x
+        x = _q(conv_a(conv_a(x, sd, f"{p}.module_list.{i}.0"), sd, f"{p}.module_list.{i}.1", store=False) + x)
     return x
 
 
@@ -135,7 +177,7 @@ def _csp_stage(x, sd, p, n):                                                    
     y2 = conv_a(x, sd, p + ".conv2")
     for i in range(n):
         q = f"{p}.resblock.{i}"
-        y2 = F.leaky_relu(y2 + conv_a(conv_a(y2, sd, q + ".conv1"), sd, q + ".conv2", act=False), 0.1)
+        y2 = _q(F.leaky_relu(y2 + conv_a(conv_a(y2, sd, q + ".conv1"), sd, q + ".conv2", act=False, store=False), 0.1))
     return conv_a(torch.cat([y1, y2], 1), sd, p + ".conv3")
 
 
@@ -151,11 +193,11 @@ def cspdarknet(sd, x, p="base"):                                                
 
 # ---- family A detectors: raw head maps, fine -> coarse --------------------------------------------
 def _pred(x, sd, p):
-    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"])
+    return _conv2d(x, sd[p + ".weight"], sd[p + ".bias"])
 
 
 def _up_bilinear(x):
-    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    return _q(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True))
 
 
 def v3tiny_heads(sd, x):                                                              # models/v3tiny.py:68-80
@@ -184,18 +226,19 @@ def _reorg2(r):                                                                 
     return r.view(b, c, 4, (h // 2) * (w // 2)).transpose(1, 2).contiguous().view(b, -1, h // 2, w // 2)
 
 
-def _cbr(x, sd, conv, bn, s=1, relu=True):
+def _cbr(x, sd, conv, bn, s=1, relu=True, store=True):
     """Conv2d(no bias) + BN(eps 1e-5) [+ ReLU] as the ResNet trunk composes them (basemodel/resnet.py:13-20)."""
     w = sd[conv + ".weight"]
-    y = _bn(F.conv2d(x, w, None, stride=s, padding=w.shape[-1] // 2), sd, bn, 1e-5)
-    return F.relu(y) if relu else y
+    y = _conv_bn(x, w, None, sd, bn, 1e-5, stride=s, padding=w.shape[-1] // 2)
+    y = F.relu(y) if relu else y
+    return _q(y) if store else y
 
 
 def _basic_block(x, sd, p, s):                                                        # basemodel/resnet.py:24-54
-    out = _cbr(_cbr(x, sd, p + ".conv1", p + ".bn1", s=s), sd, p + ".conv2", p + ".bn2", relu=False)
+    out = _cbr(_cbr(x, sd, p + ".conv1", p + ".bn1", s=s), sd, p + ".conv2", p + ".bn2", relu=False, store=False)
     if p + ".downsample.0.weight" in sd:
         x = _cbr(x, sd, p + ".downsample.0", p + ".downsample.1", s=s, relu=False)
-    return F.relu(out + x)
+    return _q(F.relu(out + x))
 
 
 def resnet18_trunk(sd, x, p="base"):                                                  # basemodel/resnet.py:96-155
@@ -252,9 +295,16 @@ def _csp_bottleneck(x, sd, p, n=3):                                             
     y1 = conv_a(x, sd, p + ".conv1")
     for i in range(n):
         y1 = conv_a(conv_a(y1, sd, f"{p}.bottleblock.{i}.conv1"), sd, f"{p}.bottleblock.{i}.conv2")
-    y1 = F.conv2d(y1, sd[p + ".conv3.weight"])
-    y2 = F.conv2d(x, sd[p + ".conv2.weight"])
-    y = F.leaky_relu(_bn(torch.cat([y1, y2], 1), sd, p + ".bn", 1e-5), 0.1)
+    w3, w2 = sd[p + ".conv3.weight"], sd[p + ".conv2.weight"]
+    if _BF16:      # the BatchNorm behind the concatenation is per channel: each half folds into the convolution producing it
+        scale = sd[p + ".bn.weight"] / torch.sqrt(sd[p + ".bn.running_var"] + 1e-5)
+        shift = sd[p + ".bn.bias"] - sd[p + ".bn.running_mean"] * scale
+        c = w3.shape[0]
+        y1 = F.conv2d(_q(y1), _q(w3 * scale[:c].view(-1, 1, 1, 1)), shift[:c])
+        y2 = F.conv2d(_q(x), _q(w2 * scale[c:].view(-1, 1, 1, 1)), shift[c:])
+        y = _q(F.leaky_relu(torch.cat([y1, y2], 1), 0.1))
+    else:
+        y = F.leaky_relu(_bn(torch.cat([_conv2d(y1, w3), _conv2d(x, w2)], 1), sd, p + ".bn", 1e-5), 0.1)
     return conv_a(y, sd, p + ".conv4")
 
 

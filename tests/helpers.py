@@ -72,3 +72,36 @@ def v5s_cfg():
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def rel_l2(a, b):
+    """||a - b||_2 / ||b||_2."""
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+PARITY_LOG = os.path.join(ROOT, "gpurun_out", "parity_report.jsonl")
+
+
+def parity(name, got, ref, tol, floor=None, floor_factor=1.25):
+    """Measured error of `got` against `ref` under both metrics -- max |a - b| / max |b| and relative L2 -- printed (pytest -s
+    or a failure shows it) and appended to gpurun_out/parity_report.jsonl, then asserted: both metrics at most `tol`, or,
+    when `floor` is given (the same tensor out of a CPU network that rounds every activation and folded weight to bf16,
+    i.e. what any layer-by-layer bf16 pipeline loses), at most floor_factor x that floor's own error."""
+    import json
+    e_max, e_l2 = rel_err(got, ref), rel_l2(got, ref)
+    rec = {"name": name, "max_norm": e_max, "rel_l2": e_l2, "tol": tol}
+    if floor is not None:
+        rec["floor_max_norm"], rec["floor_rel_l2"] = rel_err(floor, ref), rel_l2(floor, ref)
+    print("parity", json.dumps(rec))
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    if floor is None:
+        assert e_max <= tol and e_l2 <= tol, rec
+    else:
+        assert e_max <= max(tol, floor_factor * rec["floor_max_norm"]) and e_l2 <= max(tol, floor_factor * rec["floor_rel_l2"]), rec
+    return rec

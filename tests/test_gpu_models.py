@@ -1,17 +1,20 @@
 """GPU parity of whole blocks and models (product mirrors running the HIP launch list) against the golden
 vectors captured from the reference and against the oracle networks.
 
-Tolerances (relative to the largest reference magnitude of the tensor compared):
-fp32 compute path 1e-3, bf16 compute path 2e-2 for single blocks; whole bf16 networks accumulate rounding
-over 60-125 layers and are held to 5e-2 on the raw head maps.  Kept-box results are compared exactly on
-the fp32 path when both sides are fed the same decoded boxes (that is what test_gpu_ops covers); here,
-end to end, the detections are compared as sets with a box tolerance.
+Tolerances: fp32 compute path 1e-3, bf16 compute path 2e-2 -- single blocks and whole networks alike.  Every
+bf16 whole-network comparison goes through helpers.parity, which measures the error under two metrics (largest
+difference over largest reference magnitude, and relative L2), prints both, appends them to
+gpurun_out/parity_report.jsonl and asserts both.  Where a network's depth takes a bf16 pipeline beyond 2e-2 whatever
+the implementation, the comparison also carries the floor -- the same tensor out of the CPU network with every
+activation and weight rounded to bf16 (oracle.nets.bf16_storage) -- and the GPU result must stay within 1.25 x that
+floor's own error.  Kept-box results are compared exactly on the fp32 path when both sides are fed the same decoded
+boxes (that is what test_gpu_ops covers); here, end to end, the detections are compared as sets with a box tolerance.
 """
 import numpy as np
 import pytest
 import torch
 
-from helpers import FA_SPECS, build_fa, build_v5s, fa_thresholds, oracle_fa_heads, rel_err, v5s_cfg
+from helpers import FA_SPECS, build_fa, build_v5s, fa_thresholds, oracle_fa_heads, parity, rel_err, v5s_cfg
 from oracle import nets as ON
 from oracle import postproc as O
 from yolo_amd import _ffi, engine
@@ -20,6 +23,22 @@ from yolo_amd.synthetic import _gen, images, init_deterministic
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = {"fp32": 1e-3, "bf16": 2e-2}
+
+
+def v5s_floor(m, x, nc):
+    """Raw head maps (bs, na, ny, nx, no) and decoded rows z of the CPU network that keeps weights and activations in bf16."""
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad(), ON.bf16_storage():
+        heads = ON.yolov5_heads(sd, x.float().cpu(), v5s_cfg())
+    det = m.model[-1]
+    z = O.detect_decode([h.numpy() for h in heads], det.stride.tolist(), det.anchor_grid.view(3, 3, 2).cpu().numpy(), 3, nc + 5)[0]
+    return [h.view(h.shape[0], 3, nc + 5, h.shape[2], h.shape[3]).permute(0, 1, 3, 4, 2).numpy() for h in heads], z
+
+
+def fa_floor(tag, net, x):
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad(), ON.bf16_storage():
+        return [h.numpy() for h in oracle_fa_heads(tag, sd, x.float().cpu())]
 
 
 @pytest.fixture(autouse=True)
@@ -135,10 +154,9 @@ def test_own_v5_models_golden(golden, compute, tag):
     net = build_own_v5(tag).to(DEV)
     x = images(2, 128, seed=129, kind="randn").to(DEV)
     outs = net(x)
-    tol = TOL[compute] if compute == "fp32" else 5e-2
     for o, name in zip(outs, ("ys", "ym", "yl")):
         assert tuple(o.shape) == g[name].shape and o.dtype == torch.float32
-        assert rel_err(o.cpu().numpy(), g[name]) < tol, name
+        parity(f"own_{tag}_128/{compute}/{name}", o.cpu().numpy(), g[name], TOL[compute])
 
 
 # ---- YOLOv5s ------------------------------------------------------------------------------------------------------
@@ -152,15 +170,17 @@ def test_v5s_small_golden(golden, compute, nc):
     with torch.no_grad():
         z, xs = m(x)
     assert z.shape == g["z"].shape and z.dtype == torch.float32
-    tol = TOL[compute] if compute == "fp32" else 5e-2
+    tol = TOL[compute]
     # raw maps: fp32 from an fp32 plan, bf16 from a bf16 plan (as a half-precision reference returns half maps)
     assert all(t.dtype == (torch.float32 if compute == "fp32" else torch.bfloat16) for t in xs)
+    floor, zf = v5s_floor(m, x, nc) if compute == "bf16" else ([None] * 3, None)
     for i in range(3):
         assert tuple(xs[i].shape) == g[f"x{i}"].shape
-        assert rel_err(xs[i].float().cpu().numpy(), g[f"x{i}"]) < tol, f"head {i}"
+        parity(f"v5s_nc{nc}_64/{compute}/x{i}", xs[i].float().cpu().numpy(), g[f"x{i}"], tol, floor[i])
     zr = g["z"]
-    assert rel_err(z[..., 4:].cpu().numpy(), zr[..., 4:]) < tol          # probabilities
-    assert rel_err(z[..., :4].cpu().numpy(), zr[..., :4]) < tol          # boxes (pixels, scale = image size)
+    parity(f"v5s_nc{nc}_64/{compute}/z_prob", z[..., 4:].cpu().numpy(), zr[..., 4:], tol, None if zf is None else zf[..., 4:])
+    # boxes (pixels, scale = image size)
+    parity(f"v5s_nc{nc}_64/{compute}/z_box", z[..., :4].cpu().numpy(), zr[..., :4], tol, None if zf is None else zf[..., :4])
 
     def redecode(maps):
         return O.detect_decode([t.float().permute(0, 1, 4, 2, 3).reshape(t.shape[0], -1, t.shape[2], t.shape[3]).cpu().numpy()
@@ -198,15 +218,18 @@ def test_v5s_640_samples(golden, compute):
     g = golden("g6_v5s_nc80_640")
     engine.set_compute_dtype(compute)
     m = build_v5s(80).to(DEV)
+    x = images(1, 640, seed=640)
     with torch.no_grad():
-        z, xs = m(images(1, 640, seed=640).to(DEV))
+        z, xs = m(x.to(DEV))
     step = int(g["step"])
-    tol = 1e-3 if compute == "fp32" else 5e-2
+    tol = TOL[compute]
+    floor, zf = v5s_floor(m, x, 80) if compute == "bf16" else (None, None)
     for i in range(3):
         got = xs[i].float().contiguous().cpu().numpy().reshape(-1)[::step]
-        assert rel_err(got, g[f"head_sample{i}"]) < tol
+        parity(f"v5s_nc80_640/{compute}/head{i}", got, g[f"head_sample{i}"], tol,
+               None if floor is None else np.ascontiguousarray(floor[i]).reshape(-1)[::step])
     zs = z.cpu().numpy().reshape(-1)[::step]
-    assert rel_err(zs, g["z_sample"]) < tol
+    parity(f"v5s_nc80_640/{compute}/z", zs, g["z_sample"], tol, None if zf is None else zf.reshape(-1)[::step])
     if compute == "fp32":
         assert abs(float(z.double().sum()) - float(g["z_sum"])) / abs(float(g["z_sum"])) < 1e-4
 
@@ -310,10 +333,10 @@ def test_family_a_heads_golden(golden, compute, tag, size):
     net = build_fa(tag, size).to(DEV)
     x = images(1, size, seed=int(g["x_seed"]), kind="randn").to(DEV)
     heads = net.head_maps(x)
-    tol = 1e-3 if compute == "fp32" else 5e-2
-    for h, name in zip(heads, FA_SPECS[tag][3]):
+    floor = fa_floor(tag, net, x) if compute == "bf16" else [None] * len(heads)
+    for h, name, fl in zip(heads, FA_SPECS[tag][3], floor):
         assert tuple(h.shape) == g["head_" + name].shape
-        assert rel_err(h.cpu().numpy(), g["head_" + name]) < tol, name
+        parity(f"{tag}_{size}/{compute}/{name}", h.cpu().numpy(), g["head_" + name], TOL[compute], fl)
 
 
 @pytest.mark.parametrize("tag,size", [("v3tiny", 416), ("v2d19", 416), ("v3spp", 128), ("v4", 128)])
@@ -333,8 +356,9 @@ def test_family_a_heads_golden_with_split_k(golden, tag, size):
         assert any(p.splitk_ws and p.splitk_ws[0] is not None for p in plans), "no launch was split"
     finally:
         engine.set_split_k(False)
-    for h, h0, name in zip(heads, plain, FA_SPECS[tag][3]):
-        assert rel_err(h.numpy(), g["head_" + name]) < 5e-2, name
+    floor = fa_floor(tag, net, x)
+    for h, h0, name, fl in zip(heads, plain, FA_SPECS[tag][3], floor):
+        parity(f"{tag}_{size}/bf16+splitk/{name}", h.numpy(), g["head_" + name], TOL["bf16"], fl)
         assert rel_err(h.numpy(), h0.numpy()) < 2e-2, name
 
 
@@ -537,16 +561,19 @@ def test_baseline_configs_full_size(tag, size, batch):
     """YOLOv2-D19 416 bs32, YOLOv3-SPP 608 bs64, YOLOv4 608 bs64 through size-independent properties: (a) the first and
     last image's head maps against the CPU restatement of the network (fp32, 1e-3), (b) every image of the batch equals
     its own single-image run bit for bit, (c) the kept set of those images is exact against the oracle's postprocess fed
-    the same decoded boxes, (d) bf16 head maps within 5e-2 of the fp32 ones."""
+    the same decoded boxes, (d) the bf16 head maps of the first and last image against the CPU restatement (2e-2, or
+    1.25 x the error of the CPU network that keeps weights and activations in bf16)."""
     engine.set_compute_dtype("fp32")
     net = build_fa(tag, size).to(DEV)
     x = images(batch, size, seed=900 + size, kind="randn")
     xd = x.to(DEV)
     heads = [h.clone() for h in net.head_maps(xd)]
     sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    refs = {}
     for i in (0, batch - 1):
         with torch.no_grad():
             ref = oracle_fa_heads(tag, sd, x[i:i + 1])
+        refs[i] = [r[0].numpy() for r in ref]
         for h, r in zip(heads, ref):
             assert rel_err(h[i].cpu().numpy(), r[0].numpy()) < 1e-3, (tag, i)
     boxes, keep, cls, best = net.detect_batch(xd)
@@ -566,8 +593,11 @@ def test_baseline_configs_full_size(tag, size, batch):
         np.testing.assert_array_equal(best[i].cpu().numpy()[k], rs)
         np.testing.assert_array_equal(cls[i].cpu().numpy()[k], rc)
     engine.set_compute_dtype("bf16")
-    for h, h16 in zip(heads, net.head_maps(xd)):
-        assert rel_err(h16.float().cpu().numpy(), h.cpu().numpy()) < 5e-2
+    heads16 = [h.float().cpu().numpy() for h in net.head_maps(xd)]
+    for i in (0, batch - 1):
+        floor = fa_floor(tag, net, x[i:i + 1])
+        for lvl, (h16, r, fl) in enumerate(zip(heads16, refs[i], floor)):
+            parity(f"{tag}_{size}_bs{batch}/bf16/img{i}/head{lvl}", h16[i], r, TOL["bf16"], fl[0])
     engine.set_compute_dtype("fp32")
 
 
@@ -613,7 +643,7 @@ def test_c3_tail_fused_equals_separate_ops(n):
 def test_v5s_640_bs64_headline_config():
     """YOLOv5s 640x640, 64 images, bf16 -- the configuration the benchmark is quoted on -- through size-independent
     properties: (a) the raw head maps of the first and last image against the CPU restatement of the network (bf16 bar
-    for whole networks, 5e-2), (b) every image of the batch equals its own single-image run bit for bit (the batch only
+    2e-2, or 1.25 x the error of the CPU network that keeps weights and activations in bf16), (b) every image of the batch equals its own single-image run bit for bit (the batch only
     changes tile shapes and grids, never the order of a sum), (c) z is exactly the decode of the fp32 raw maps, and the
     bf16 raw maps a bf16 plan returns are those fp32 maps rounded,
     (d) NMS (validation regime) of two images is exact against the oracle fed the same decoded rows, (e) the same batch
@@ -633,9 +663,11 @@ def test_v5s_640_bs64_headline_config():
     for i in (0, 63):                                                                  # (a)
         with torch.no_grad():
             ref = ON.yolov5_heads(sd, x[i:i + 1], v5s_cfg())
+            with ON.bf16_storage():
+                floor = ON.yolov5_heads(sd, x[i:i + 1], v5s_cfg())
         for lvl, r in enumerate(ref):
             got = xs[lvl][i].float().permute(0, 3, 1, 2).reshape(r.shape[1:]).cpu().numpy()    # (na, ny, nx, no) -> (na*no, ny, nx)
-            assert rel_err(got, r[0].numpy()) < 5e-2, (i, lvl)
+            parity(f"v5s_nc80_640_bs64/bf16/img{i}/head{lvl}", got, r[0].numpy(), TOL["bf16"], floor[lvl][0].numpy())
     with torch.no_grad():                                                              # (b)
         for i in range(64):
             z1, x1 = m(xd[i:i + 1])
@@ -687,7 +719,7 @@ def test_v5s_fuse_matches_unfused_and_reference(golden, compute):
     engine.set_compute_dtype(compute)
     m = build_v5s(20).to(DEV)
     x = torch.from_numpy(g["x"]).to(DEV)
-    tol = 1e-3 if compute == "fp32" else 5e-2
+    tol = TOL[compute]
     with torch.no_grad():
         z0 = m(x)[0].clone()
         plan0 = next(iter(m._plans().plans.values()))
@@ -699,9 +731,9 @@ def test_v5s_fuse_matches_unfused_and_reference(golden, compute):
     assert len(plans) == 1 and plans[0] is not plan0                  # the plan was rebuilt from the fused weights
     assert [k for k, _ in plans[0].g.ops] == [k for k, _ in plan0.g.ops]   # ... with the same fused kernels
     assert rel_err(z1.cpu().numpy(), z0.cpu().numpy()) < (1e-3 if compute == "fp32" else 2e-2)
-    assert rel_err(z1[..., 4:].cpu().numpy(), g["z_fused"][..., 4:]) < tol
-    assert rel_err(z1[..., :4].cpu().numpy(), g["z_fused"][..., :4]) < tol
-    assert rel_err(z0.cpu().numpy(), g["z_plain"]) < tol
+    parity(f"v5s_fuse/{compute}/z_fused_prob", z1[..., 4:].cpu().numpy(), g["z_fused"][..., 4:], tol)
+    parity(f"v5s_fuse/{compute}/z_fused_box", z1[..., :4].cpu().numpy(), g["z_fused"][..., :4], tol)
+    parity(f"v5s_fuse/{compute}/z_plain", z0.cpu().numpy(), g["z_plain"], tol)
 
 
 def test_v5s_forward_augment_reference(golden):

@@ -371,6 +371,31 @@ def test_two_rank_gloo_val_run_equals_one_process(tmp_path):
         assert two == one
 
 
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks, which rendezvous (gloo here), run the
+    detection all-gather on their own detections and print ONE line from rank 0 with n_gpus = 2 and both ranks seen in
+    the gathered image ids; a WORLD_SIZE that contradicts --gpus fails loudly.  (--mock-gpu: this machine has no GPU,
+    the step itself is a stand-in.)"""
+    import json as _json
+    env = dict(os.environ, YDET_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mock-gpu", "--batch", "6", "--steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = _json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["launcher"] == "self" and j["mock"] is True
+    ex = j["exchange"]
+    assert ex["backend"] == "gloo" and ex["ranks_seen"] == 2 and ex["images"] == 12 and 0.0 < ex["map50"] <= 1.0
+    bad = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=60)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+    one = subprocess.run(cmd[:2] + ["--gpus", "1", "--mock-gpu", "--batch", "4", "--steps", "1"], capture_output=True, text=True,
+                         env=env, timeout=120)
+    assert one.returncode == 0 and _json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
 def test_results_file_rounding_without_strings():
     """The vectorised rounding equals the reference's write-then-parse round trip ('{:.3f}' score, '{:.1f}' of x + 1),
     including exact halves (x.25 -> half to even on the exact value)."""

@@ -278,3 +278,34 @@ def test_diou_non_max_suppression_golden(golden, tag):
         np.testing.assert_array_equal(o[:, 4:], ref[:, 4:])
         np.testing.assert_array_equal(np.isnan(o), np.isnan(ref))
         np.testing.assert_allclose(np.nan_to_num(o[:, :4]), np.nan_to_num(ref[:, :4]), rtol=2e-6, atol=1e-4)
+
+
+def test_bf16_storage_floor_is_off_by_default_and_small():
+    """oracle.nets.bf16_storage: outside the context the networks are the plain fp32 ones (bit for bit before and after a
+    use of it); inside, weights and activations are rounded to bf16 and the head maps move by a fraction of a percent on
+    a small input -- the floor the bf16 GPU path is measured against."""
+    import torch
+    from helpers import build_fa, build_v5s, oracle_fa_heads, rel_l2, v5s_cfg
+    from oracle import nets as ON
+    from yolo_amd.synthetic import images
+    m = build_v5s(20)
+    sd = {k: v.detach().float() for k, v in m.state_dict().items()}
+    x = images(1, 64, seed=64)
+    with torch.no_grad():
+        a = ON.yolov5_heads(sd, x, v5s_cfg())
+        with ON.bf16_storage():
+            f = ON.yolov5_heads(sd, x, v5s_cfg())
+        b = ON.yolov5_heads(sd, x, v5s_cfg())
+    for u, v, w in zip(a, b, f):
+        assert torch.equal(u, v)
+        assert 1e-4 < rel_l2(w.numpy(), u.numpy()) < 2e-2
+    for tag in ("v4", "v2r50", "v3spp"):
+        net = build_fa(tag, 64)
+        sd = {k: v.detach().float() for k, v in net.state_dict().items()}
+        x = images(1, 64, seed=3, kind="randn")
+        with torch.no_grad():
+            a = oracle_fa_heads(tag, sd, x)
+            with ON.bf16_storage():
+                f = oracle_fa_heads(tag, sd, x)
+        for u, w in zip(a, f):
+            assert 1e-4 < rel_l2(w.numpy(), u.numpy()) < 3e-2, tag

@@ -13,8 +13,12 @@ sources can be compared line by line.  FETCH_SIZE / WRITE_SIZE are kilobytes; on
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # noqa: E402  (the stamp bench.py compares with the tree it runs: stale summaries read as null)
 
 
 def label_of(name):
@@ -85,7 +89,7 @@ def traffic(fetch_csv, write_csv, batch, size):
         d["hbm_bytes_per_launch"] = round((2.0 * d["fetch_kb_raw"] + d["write_kb"]) * 1024)
     print(json.dumps(dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --no-cpu` (separate runs); "
                                  "kilobytes per launch, read side doubled (gfx950 tallies 128-B requests at 64 B)",
-                          batch=int(batch), size=int(size), kernels=out), indent=1))
+                          batch=int(batch), size=int(size), csrc_sha1=csrc_hash(), kernels=out), indent=1))
 
 
 def counters(paths):
@@ -120,7 +124,8 @@ def counters(paths):
                 if c in d:
                     d[key] = round(d[c] * 4.0 / simd_cycles, 4)
     print(json.dumps(dict(source="rocprofv3 --pmc passes of `bench.py --no-cpu --streams 1` (counters only, no trace in the same "
-                                 "run); means per launch; GRBM_GUI_ACTIVE is the sum over the 8 XCDs", kernels=agg), indent=1))
+                                 "run); means per launch; GRBM_GUI_ACTIVE is the sum over the 8 XCDs", csrc_sha1=csrc_hash(), kernels=agg),
+                     indent=1))
 
 
 if __name__ == "__main__":
