@@ -340,8 +340,11 @@ int ydet_nms_v5_static(const float* pred, int N, int nboxes, int no, float conf_
  * conf_thres < 0.01, :352-359) or for the first-maximum class only (:360-362); descending score (:371; equal scores:
  * lower box first).  Per class the first 500 rows (:390-391) go through `method`:
  *   YDET_NMS2_HARD_BATCH / YDET_NMS2_HARD  torchvision's rule (suppress IoU > nms_thres), :377 / :395; the batch form
- *                          offsets boxes by class * (largest coordinate + 1) and has no 500-row limit: a class with
- *                          more than 2048 candidates sets *overflow
+ *                          offsets boxes by class * (largest coordinate + 1) IN FP32 for any number of candidates
+ *                          (torchvision's coordinate-offset formulation of batched_nms; releases that switch to a
+ *                          per-class loop without offsets above 4000 boxes can differ from it at the IoU threshold
+ *                          by the rounding of the offset coordinates, ~0.004 px at offsets near 5e4) and has no
+ *                          500-row limit: a class with more than 2048 candidates sets *overflow
  *   YDET_NMS2_HARD_MYSELF  :398-405 (keep bbox_iou2 < nms_thres)      YDET_NMS2_DIOU  :447-454 (DIoU instead)
  *   YDET_NMS2_AND          :408-413 (a head needs a neighbour with IoU > 0.5)
  *   YDET_NMS2_MERGE        :416-425 (score-weighted mean of the head's cluster; nms_thres must be below 1)

@@ -482,6 +482,51 @@ def test_two_streams_have_their_own_plans():
         assert torch.equal(za, ref_a) and torch.equal(zb, ref_b)
 
 
+def test_outputs_survive_later_forwards():
+    """The reference's modules return fresh tensors (yolov5_official/model.py:56-81, models/v3tiny.py:137-154): a caller may
+    keep one batch's outputs while the next batches run.  Everything the accelerated modules hand back is the caller's
+    too -- nothing aliases a plan's activation arena: outputs of a first forward pass are unchanged after two more passes
+    of the same shape on other images (same plan, same stream)."""
+    engine.set_compute_dtype("bf16")
+    m = build_v5s(20).to(DEV)
+    xa, xb, xc = (images(4, 128, seed=s).to(DEV) for s in (31, 32, 33))
+    with torch.no_grad():
+        za, xsa = m(xa)
+        snap = [za.clone()] + [t.clone() for t in xsa]
+        zb, _ = m(xb)
+        zc, _ = m(xc)
+        torch.cuda.synchronize()
+        assert len(m._plans().plans) == 1
+        assert not torch.equal(zb, za) and not torch.equal(zc, za)
+        assert all(torch.equal(a, b) for a, b in zip([za] + list(xsa), snap))
+    net = build_fa("v3tiny", 128).to(DEV)
+    ya, yb = images(2, 128, seed=41, kind="randn").to(DEV), images(2, 128, seed=42, kind="randn").to(DEV)
+    ha = net.head_maps(ya)
+    da = net.detect_batch(ya)
+    snap = [t.clone() for t in list(ha) + list(da)]
+    net.head_maps(yb)
+    net.detect_batch(yb)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(list(ha) + list(da), snap))
+    own = build_own_v5("v5").to(DEV)
+    oa = own(images(2, 128, seed=51, kind="randn").to(DEV))
+    snap = [t.clone() for t in oa]
+    own(images(2, 128, seed=52, kind="randn").to(DEV))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(oa, snap))
+    # a graph-level plan whose declared output lives in the activation arena: copied out on return
+    gr = engine.Graph(DEV, "bf16")
+    blk = _block("b_conv3s2").to(DEV)
+    gr.output("y", engine.lower_any(gr, blk, gr.input_nchw(2, 16, 16, 16)))
+    plan = gr.finalize()
+    g = _gen(9, "outlife")
+    y1 = plan.run(torch.randn(2, 16, 16, 16, generator=g).to(DEV))["y"]
+    keep = y1.clone()
+    plan.run(torch.randn(2, 16, 16, 16, generator=g).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, keep)
+
+
 def test_val_run_device_tail_matches_host_recomputation():
     """yolov5_official/val.py:27-186 end to end on synthetic data: val.run (TP matching of all images in one launch on
     the device) against the same metrics recomputed on the host with the oracle's process_batch."""

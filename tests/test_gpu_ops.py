@@ -660,6 +660,30 @@ def test_grouped_modules_lower():
         assert rel_err(out["y"].float().cpu(), ref) < 1e-3, name
 
 
+def test_c3spp_lowers_and_numpy_nms_is_exported(golden):
+    """C3SPP (yolov5_official/modules.py:262-268: a C3 whose middle is one SPP block) runs on the GPU path and matches its
+    own torch forward; models.common offers Contract / Expand / Concat; yolov5_official.utils.nms (:551-578, the numpy
+    greedy NMS) gives the reference's recorded kept list."""
+    from yolo_amd.models import common as C
+    from yolo_amd.synthetic import init_deterministic
+    from yolo_amd.yolov5_official import utils as U
+    from yolo_amd.yolov5_official.modules import C3SPP, Concat, Contract, Expand
+    for compute, tol in (("fp32", 1e-3), ("bf16", 2e-2)):
+        mod = C3SPP(64, 64)
+        init_deterministic(mod, seed=3)
+        mod.eval()
+        x = torch.randn(2, 64, 20, 24, generator=_gen(4, "c3spp")).bfloat16().float()
+        with torch.no_grad():
+            ref = mod(x)
+        out = _run_graph(lambda gr, ins: gr.to_nchw(mod.lower(gr, ins[0]), "y"), x, compute=compute)
+        assert rel_err(out["y"].float().cpu(), ref) < tol, compute
+    assert (C.Contract, C.Expand, C.Concat) == (Contract, Expand, Concat) and issubclass(C.C3SPP, C.C3)
+    t = torch.arange(2 * 4 * 6 * 6, dtype=torch.float32).view(2, 4, 6, 6)
+    assert torch.equal(Expand(2)(Contract(2)(t)), t) and Contract(2)(t).shape == (2, 16, 3, 3)
+    g = golden("g3_postprocess_0")
+    assert U.nms(g["bb"], g["scores"][:, 0], float(g["thr"])) == [int(i) for i in g["nms_keep_class0_scores"]]
+
+
 # ---- K split over workgroups (opt-in) ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("geom", [(1, 256, 512, 3, 1, 13, 13, False), (1, 1024, 256, 1, 1, 13, 13, False), (2, 512, 256, 3, 2, 26, 22, False),
                                   (1, 256, 256, 3, 1, 20, 20, True), (3, 1024, 512, 1, 1, 7, 9, True), (1, 128, 192, 5, 1, 11, 11, False)])

@@ -340,10 +340,31 @@ for b in range(N_IMG // BS):
         for r in top:
             tg.append([k, float(r[5:].argmax()), *(r[:4] / 64.0).tolist()])
     batches.append((img, torch.tensor(tg).reshape(-1, 6), [f"im{b}_{k}.jpg" for k in range(BS)], [((64, 64), ((1.0, 1.0), (0.0, 0.0)))] * BS))
-res, maps, _ = V.run(dict(nc=NC), model=FakeModel(), dataloader=batches, device="cpu", half=False, conf_thres=0.05, iou_thres=0.5)
+mode = sys.argv[3] if len(sys.argv) > 3 else "list"
+loader = batches
+if mode == "dataloader":      # a torch DataLoader over an indexable dataset: re-built per rank over its own image range
+    class DS(torch.utils.data.Dataset):
+        touched = []
+        def __len__(self):
+            return N_IMG
+        def __getitem__(self, i):
+            DS.touched.append(i)
+            b, k = divmod(i, BS)
+            img, tg, paths, shapes = batches[b]
+            return img[k], tg[tg[:, 0] == k, 1:], paths[k], shapes[k]
+    def collate(items):
+        imgs, tgs, paths, shapes = zip(*items)
+        tg = torch.cat([torch.cat([torch.full((len(t), 1), float(k)), t], 1) for k, t in enumerate(tgs)], 0)
+        return torch.stack(imgs), tg, list(paths), list(shapes)
+    loader = torch.utils.data.DataLoader(DS(), batch_size=BS, collate_fn=collate)
+elif mode == "generator":
+    loader = (b for b in batches)
+res, maps, _ = V.run(dict(nc=NC), model=FakeModel(), dataloader=loader, device="cpu", half=False, conf_thres=0.05, iou_thres=0.5)
 own = list(range(*[x * BS for x in yd.shard_range(len(batches), rank, world)]))
+if mode == "dataloader":
+    assert sorted(set(DS.touched)) == own, (DS.touched, own)     # a rank never loads an image it does not own
 assert FakeModel.seen == own, (FakeModel.seen, own)           # a rank runs only its contiguous range of images
-json.dump(dict(res=[float(v) for v in res], maps=[float(v) for v in maps]), open(os.path.join(sys.argv[2], f"val{rank}_{world}.json"), "w"))
+json.dump(dict(res=[float(v) for v in res], maps=[float(v) for v in maps]), open(os.path.join(sys.argv[2], f"val{rank}_{world}_{mode}.json"), "w"))
 if world > 1:
     torch.distributed.barrier(); torch.distributed.destroy_process_group()
 '''
@@ -359,16 +380,19 @@ def test_two_rank_gloo_val_run_equals_one_process(tmp_path):
         env.pop(k, None)
     r1 = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path)], capture_output=True, text=True, env=env, timeout=240)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                         "--master-addr", "127.0.0.1", "--master-port", "29613", str(script), ROOT, str(tmp_path)],
-                        capture_output=True, text=True, env=dict(env, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613"), timeout=240)
-    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     import json as _json
-    one = _json.load(open(tmp_path / "val0_1.json"))
+    one = _json.load(open(tmp_path / "val0_1_list.json"))
     assert one["res"][2] > 0.0, "the synthetic set must produce a non-trivial mAP"
-    for rank in (0, 1):
-        two = _json.load(open(tmp_path / f"val{rank}_2.json"))
-        assert two == one
+    # a list of batches (walked lazily), a torch DataLoader over an indexable dataset (re-built per rank over its own image
+    # range; every rank knows the shard sizes, so the gather needs no size exchange) and a generator (drawn first)
+    for port, mode in ((29613, "list"), (29615, "dataloader"), (29617, "generator")):
+        r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                             "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(tmp_path), mode],
+                            capture_output=True, text=True, env=dict(env, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)), timeout=240)
+        assert r2.returncode == 0, mode + r2.stdout[-2000:] + r2.stderr[-4000:]
+        for rank in (0, 1):
+            two = _json.load(open(tmp_path / f"val{rank}_2_{mode}.json"))
+            assert two == one, mode
 
 
 def test_bench_gpus_2_launches_two_ranks_itself():

@@ -47,6 +47,20 @@ def test_static_scratch_nms_equals_workspace_nms():
         assert int(cnt.min()) >= 0 and int(cnt.max()) > 0
         del det, cnt, ref_det, ref_cnt
         assert torch.cuda.memory_allocated(DEV) == before
+    # "allocates nothing" at the level of the driver, not just of torch's caching allocator (which never sees a hipMalloc
+    # made inside the library): with the outputs allocated beforehand, the free device memory the driver reports is the
+    # same before and after calls of either size
+    for pred, kw in ((big, dict(conf=0.001, iou=0.6, multi_label=True)), (small, dict(conf=0.25, iou=0.45, multi_label=False))):
+        det = torch.empty(pred.shape[0], 300, 6, device=DEV)
+        cnt = torch.empty(pred.shape[0], device=DEV, dtype=torch.int32)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(DEV)[0]
+        with torch.cuda.device(DEV):
+            rc = _ffi.lib().ydet_nms_v5_static(pred.data_ptr(), pred.shape[0], pred.shape[1], pred.shape[2], kw["conf"], kw["iou"],
+                                               int(kw["multi_label"]), 0, 300, 300, 4096.0, None, None, det.data_ptr(),
+                                               cnt.data_ptr(), _ffi.current_stream())
+        torch.cuda.synchronize()
+        assert rc == 0 and torch.cuda.mem_get_info(DEV)[0] == free0
 
 
 def test_static_scratch_nms_rejects_oversize_and_bad_arguments():

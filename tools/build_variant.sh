@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds a variant of libydet.so for A/B timing (tools/ab_conv.py):
-#   tools/build_variant.sh <name> <conv|conv_big> [<git rev> | -] [extra hipcc flags ...]
+#   tools/build_variant.sh <name> <conv|conv_pw|...> [<git rev> | -] [extra hipcc flags ...]
 # -> tools/bin/libydet_<name>.so (that one source recompiled, the other objects taken from build/csrc as they are).
 set -e
 cd "$(dirname "$0")/.."

@@ -420,17 +420,11 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     auto issue = [&](int stage) {
         char* dst = smem + stage * STAGE + wave * 1024;
         const long long woff = wbase + (long long)ktile * BK * (long long)sizeof(TIN);
-#ifdef YDET_EXP_SKIP_W
-        if (ktile == 0)
-#endif
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + woff),
                                              (__attribute__((address_space(3))) void*)(dst + j * (NW * 1024)), 16, 0, 0);
         const bool from_up = c0 < a.up_C;      // workgroup-uniform (pointwise convs only: tap stays 0)
-#ifdef YDET_EXP_SKIP_PIX   // timing experiment only: pixel rows fetched for the first tap of each channel block only
-        if (tap == 0 || a.KH == 1)
-#endif
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const bool ok = (xmask[j] >> tap) & 1u;
@@ -496,9 +490,6 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
         const char* ws = smem + (kt % NSTAGE) * STAGE + (wn * WN) * RB;
         const char* xs = smem + (kt % NSTAGE) * STAGE + WROWS * RB + (wm * WM) * RB;
         frag_t fa[KSUB][FN], fb[KSUB][FM];
-#ifdef YDET_EXP_NO_LDSREAD
-        if (kt == 0) {
-#endif
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk) {
 #pragma unroll
@@ -506,15 +497,9 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
 #pragma unroll
             for (int j = 0; j < FM; ++j) fb[kk][j] = *reinterpret_cast<const frag_t*>(xs + fr_off[kk] + j * 16 * RB);
         }
-#ifdef YDET_EXP_NO_LDSREAD
-        }
-#endif
         asm volatile("" ::: "memory");   // keep the reads above the refill
         // every wave is past its reads of stage (kt - 1) % NSTAGE: refill it with tile kt + NSTAGE - 1
         if (kt + NSTAGE - 1 < nk) issue((kt + NSTAGE - 1) % NSTAGE);
-#ifdef YDET_EXP_NO_MFMA
-        if (kt == 0)
-#endif
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
@@ -625,7 +610,6 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
                 const float4 b = *reinterpret_cast<const float4*>(cst + chan(i));
                 acc[i][j][0] += b.x; acc[i][j][1] += b.y; acc[i][j][2] += b.z; acc[i][j][3] += b.w;
             }
-#ifndef YDET_EXP_NO_RAWST
             if constexpr (PERM) {
 #pragma unroll
                 for (int sp = 0; sp < FN / 2; ++sp) {
@@ -644,7 +628,6 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
                                                     reinterpret_cast<f32x4*>(yrow + c0 * sizeof(TOUT)));
                 }
             }
-#endif
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -739,9 +722,6 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
                         for (int u = 0; u < ZU; ++u) {
                             const int k = k0 + u * NT;
                             if (k < total4) {
-#ifdef YDET_EXP_NO_ZST
-                                if (v[u].x != 12345.678f) continue;
-#endif
                                 const int an = div_small(k, per4, rper4);
                                 __builtin_nontemporal_store(f32x4{v[u].x, v[u].y, v[u].z, v[u].w},
                                                             reinterpret_cast<f32x4*>(zb + (size_t)(unsigned)(an * an_step + (k - an * per4) * 4)));
@@ -941,12 +921,11 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
                           (!a.res || (a.res_ld % (16 / (int)sizeof(TIN)) == 0 && a.res_coff % (16 / (int)sizeof(TIN)) == 0)))
                              ? 1
                              : 0;
-        if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
-            static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST>),
-                hipFuncAttributeMaxDynamicSharedMemorySize,
-                (int)(NST * (size_t)(WROWS + BM) * (KCH * 16) + 3 * BN * sizeof(float)));
-            if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation and device
+            static unsigned char optin[kMaxDevices];
+            const int rc = raise_dynamic_lds_limit(
+                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST>), (int)lds_dma, optin, "conv");
+            if (rc != YDET_OK) return rc;
         }
         if (a.y2 && !a.lds_epilogue) return fail(YDET_ERR_ARG, "conv: a second destination needs 16-byte aligned output slices");
         hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST>), dim3((unsigned)nblk),
@@ -1021,7 +1000,6 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
     }
     if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
         if (conv_pw_takes(a)) return launch_conv_pw(a, stream);
-        if (conv_big_takes(a)) return launch_conv_big(a, stream);
     }
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
     if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
@@ -1302,10 +1280,10 @@ static int launch_head_tile(const ConvArgs& a0, const HeadArgs& h, hipStream_t s
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(YDET_ERR_ARG, "head_conv_decode: grid of %lld blocks", nblk);
     const int ring = NST * (BN + BM) * 64, tile = WM * (BN + 4) * 4;
     const int lds = (tile > ring ? tile : ring) + 3 * BN * (int)sizeof(float) + 3 * BM * 4 + 16 * 4;
-    static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TRAW, BN, BM, 4, WARPS_M, true, 4, NST>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "head_conv_decode: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    static unsigned char optin[kMaxDevices];
+    const int rc = raise_dynamic_lds_limit(reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TRAW, BN, BM, 4, WARPS_M, true, 4, NST>), lds,
+                                           optin, "head_conv_decode");
+    if (rc != YDET_OK) return rc;
     hipLaunchKernelGGL((conv_dma_kernel<TIN, TRAW, BN, BM, 4, WARPS_M, true, 4, NST>), dim3((unsigned)nblk), dim3(256 * WARPS_M), lds,
                        stream, a, h);
     YDET_CHECK_LAUNCH("conv_dma_kernel<head>");

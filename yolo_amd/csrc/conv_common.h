@@ -1,4 +1,4 @@
-// Pieces shared by the convolution kernels of libydet.so (conv.hip, conv_big.hip): the launch arguments, the LDS
+// Pieces shared by the convolution kernels of libydet.so (conv.hip, conv_pw.hip): the launch arguments, the LDS
 // image helpers, the MFMA wrappers and the epilogue arithmetic.  gfx950 only.
 #pragma once
 #include <math.h>
@@ -167,11 +167,6 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-
-// The big-tile kernel of conv_big.hip (bf16 -> bf16, at least 128 output channels, one workgroup per CU): whether it
-// takes the launch, and the launch itself.
-bool conv_big_takes(const ConvArgs& a);
-int launch_conv_big(const ConvArgs& a, hipStream_t stream);
 
 // The streaming 1x1 kernel of conv_pw.hip (bf16 -> bf16, 128 or 256 input channels, many pixels; bit-identical to the
 // tiled kernel): whether it takes the launch, and the launch itself.

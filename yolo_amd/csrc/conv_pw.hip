@@ -196,9 +196,11 @@ int launch_pw(const ConvArgs& a, hipStream_t stream) {
     g.tiles_n = (a.Cout + PW_BN - 1) / PW_BN;
     g.wtiles = (a.M + 16 * FM - 1) / (16 * FM);
     // every wave of a channel tile gets the same number of wave tiles (+- 1)
-    long long slots = (160 * 1024) / LDS;
+    const DeviceInfo dev = current_device_info();
+    long long slots = dev.lds_per_cu / LDS;
     if (slots > (MINW * 4) / PW_NW) slots = (MINW * 4) / PW_NW;
-    long long gm = slots * 256 / g.tiles_n;
+    if (slots < 1) slots = 1;
+    long long gm = slots * dev.cus / g.tiles_n;
     const long long need = (g.wtiles + PW_NW - 1) / PW_NW;
     if (gm > need) gm = need;
     if (gm < 1) gm = 1;
@@ -207,14 +209,14 @@ int launch_pw(const ConvArgs& a, hipStream_t stream) {
     g.gm = (int)gm;
     const unsigned grid = (unsigned)(gm * g.tiles_n);
     if (a.up_C) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NK, FM, PW_NW, MINW, true>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        static unsigned char optin[kMaxDevices];
+        const int rc = raise_dynamic_lds_limit(reinterpret_cast<const void*>(&conv_pw_kernel<NK, FM, PW_NW, MINW, true>), LDS, optin, "conv_pw");
+        if (rc != YDET_OK) return rc;
         hipLaunchKernelGGL((conv_pw_kernel<NK, FM, PW_NW, MINW, true>), dim3(grid), dim3(64 * PW_NW), LDS, stream, a, g);
     } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NK, FM, PW_NW, MINW, false>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (attr != hipSuccess) return fail(YDET_ERR_LAUNCH, "conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        static unsigned char optin[kMaxDevices];
+        const int rc = raise_dynamic_lds_limit(reinterpret_cast<const void*>(&conv_pw_kernel<NK, FM, PW_NW, MINW, false>), LDS, optin, "conv_pw");
+        if (rc != YDET_OK) return rc;
         hipLaunchKernelGGL((conv_pw_kernel<NK, FM, PW_NW, MINW, false>), dim3(grid), dim3(64 * PW_NW), LDS, stream, a, g);
     }
     YDET_CHECK_LAUNCH("conv_pw_kernel");

@@ -1440,7 +1440,6 @@ constexpr size_t kStaticNmsBytes = (size_t)YDET_NMS_V5_STATIC_BYTES;
 static __device__ __align__(256) unsigned char g_nms_scratch[kStaticNmsBytes];
 
 namespace {
-constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 void* g_scratch_ptr[kMaxDevices];      // per device: address of that device's copy of g_nms_scratch (null: not asked yet)
 

@@ -25,6 +25,30 @@ int fail(int code, const char* fmt, ...) {
 }
 void clear_error() { g_err[0] = 0; }
 
+DeviceInfo current_device_info() {
+    static DeviceInfo info[kMaxDevices];       // cus == 0: not asked yet (racing first calls write the same values)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return DeviceInfo{256, 160 * 1024};
+    if (info[dev].cus == 0) {
+        DeviceInfo d{256, 160 * 1024};
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) d.cus = v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v > 0) d.lds_per_cu = v;
+        info[dev] = d;
+    }
+    return info[dev];
+}
+
+int raise_dynamic_lds_limit(const void* kernel, int bytes, unsigned char (&done)[kMaxDevices], const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return fail(YDET_ERR_LAUNCH, "%s: no current device", what);
+    if (done[dev]) return YDET_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(YDET_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit to %d bytes: %s", what, bytes, hipGetErrorString(e));
+    done[dev] = 1;
+    return YDET_OK;
+}
+
 }  // namespace ydet
 
 extern "C" const char* ydet_last_error(void) { return ydet::g_err; }
@@ -143,7 +167,7 @@ static int run_ops_impl(const ydet_op* ops, int n_ops, hipStream_t s, ydet_timer
 // the GPU), so that two host threads on different caller streams cannot interleave their fork / wait / join on the
 // shared events; their lists still share the side streams, i.e. run one call after the other there.
 namespace {
-constexpr int kMaxLists = 4, kMaxDevices = 64;
+constexpr int kMaxLists = 4;
 struct SidePool {
     bool ready = false;
     hipStream_t side[kMaxLists - 1];
@@ -155,12 +179,12 @@ struct PoolGuard {
     explicit PoolGuard(pthread_mutex_t* mm) : m(mm) { pthread_mutex_lock(m); }
     ~PoolGuard() { pthread_mutex_unlock(m); }
 };
-SidePool g_pool[kMaxDevices];
+SidePool g_pool[ydet::kMaxDevices];
 pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
 
 SidePool* side_pool() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ydet::kMaxDevices) return nullptr;
     pthread_mutex_lock(&g_pool_lock);
     SidePool* p = &g_pool[dev];
     if (!p->ready) {

@@ -87,6 +87,20 @@ __device__ __forceinline__ int div_small(int x, int d, float rd) {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- per-device bookkeeping (runtime.hip) ---------------------------------------------------------------------------
+// One process may drive several GPUs; whatever the library remembers about "the device" is kept per device ordinal.
+constexpr int kMaxDevices = 64;
+struct DeviceInfo {
+    int cus;          // compute units
+    int lds_per_cu;   // bytes of LDS a CU offers its resident workgroups
+};
+// Properties of the calling thread's current device (queried once per device); 256 CUs / 160 KB when the query fails.
+DeviceInfo current_device_info();
+// A kernel that takes more than 64 KB of dynamic LDS must be opted in (hipFuncAttributeMaxDynamicSharedMemorySize), and
+// the opt-in holds for the device that was current when it was made: `done` is the caller's per-kernel flag array
+// (one static array of kMaxDevices per kernel instantiation), set once the current device has been opted in.
+int raise_dynamic_lds_limit(const void* kernel, int bytes, unsigned char (&done)[kMaxDevices], const char* what);
+
 }  // namespace ydet
 
 // Internal launchers shared by the public entry points and ydet_run_ops.

@@ -56,29 +56,30 @@ def all_gather_rows(t):
     return torch.cat([out[r * m: r * m + c] for r, c in enumerate(counts)], 0)
 
 
-def all_gather_detections(det, count, image_id, total=None):
+def all_gather_detections(det, count, image_id, total=None, sizes=None):
     """det [B, max_det, 6] fp32, count [B] int32, image_id [B] int64 (global image indices) of this rank's shard ->
     the same three tensors for the whole set, sorted by image id.
 
     ONE collective: every rank packs its rows as [detections | count | image id] (the integers ride as raw bits in
-    fp32 lanes), pads them to the largest shard and calls all_gather_into_tensor once.  With `total` (the number of
-    images of the whole set, sharded contiguously by shard_range) the pad length and every rank's row count follow
-    from arithmetic: no size exchange and no host synchronisation.  Without it the largest shard is found by one
-    all-reduce(MAX) and the rows are picked by their (non-negative) image id."""
+    fp32 lanes), pads them to the largest shard and calls all_gather_into_tensor once.  When every rank knows every
+    shard's size -- `sizes` (images per rank, contiguous ranges in rank order), or `total` (images of the whole set,
+    sharded by shard_range) -- the pad length follows from arithmetic: no size exchange and no host synchronisation.
+    Without either the largest shard is found by one all-reduce(MAX) and the rows are picked by their (non-negative)
+    image id."""
     rank, ws = world()
     if ws == 1:
         order = torch.argsort(image_id)
         return det[order], count[order], image_id[order]
     B, max_det = det.shape[0], det.shape[1]
-    if total is not None:
+    if sizes is None and total is not None:
         sizes = [shard_range(total, r, ws)[1] - shard_range(total, r, ws)[0] for r in range(ws)]
-        assert sizes[rank] == B, f"rank {rank} holds {B} images, its contiguous shard has {sizes[rank]}"
-        m = max(sizes)
+    if sizes is not None:
+        assert len(sizes) == ws and sizes[rank] == B, f"rank {rank} holds {B} images, its shard is listed with {sizes[rank]}"
+        m = max(max(sizes), 1)
     else:
         mt = torch.tensor([B], device=det.device, dtype=torch.int64)
         dist.all_reduce(mt, op=dist.ReduceOp.MAX)
-        m = int(mt.item())
-        sizes = None
+        m = max(int(mt.item()), 1)
     width = max_det * 6 + 2
     packed = det.new_zeros((m, width), dtype=torch.float32)
     packed[:B, : max_det * 6] = det.reshape(B, max_det * 6).float()

@@ -492,7 +492,7 @@ class Graph:
         channels (bf16): both become one "rgb_conv" op that reads the NCHW image directly."""
         if self.dt != _ffi.BF16:
             return
-        for idx, (kind, e) in enumerate(list(self.ops)):
+        for kind, e in list(self.ops):       # (positions shift as ops are merged: an op is found again by identity)
             if kind != "nchw2nhwc" or e["focus"] or e["C"] != 3:
                 continue
             root = e["y"].resolve()[0]
@@ -518,6 +518,7 @@ class Graph:
             b4[:pc.cout_pad] = pc.b
             npc = PackedConv(w4.contiguous(), b4, 4, pc.Cout, 3, 3, 64, w4.shape[0], cin_real=3)
             self.keep.append(npc)
+            idx = next(i for i, (_, r) in enumerate(self.ops) if r is e)
             self.ops[idx] = ("rgb_conv", dict(y=y, pc=npc, N=e["N"], C=3, H=e["H"], W=e["W"], act=A["act"], slope=A["slope"],
                                               src_dtype=e["src_dtype"], pc_src=pc))
             j = next(i for i, (_, r) in enumerate(self.ops) if r is A)
@@ -530,7 +531,7 @@ class Graph:
         is taken in the convolution's epilogue and the full-size map is never written."""
         if not _fuse_rgb_pool or self.dt != _ffi.BF16:
             return
-        for idx, (kind, e) in enumerate(list(self.ops)):
+        for kind, e in list(self.ops):
             if kind != "rgb_conv" or e["H"] % 2 or e["W"] % 2 or e.get("pool"):
                 continue
             root, off = e["y"].resolve()
@@ -582,7 +583,8 @@ class Graph:
                 ts = [t for t in ts if t is not a["x"]] + [a["pre"]["x"]]   # (the follower's own input no longer exists)
             return ts
 
-        for idx, (kind, e) in enumerate(list(self.ops)):
+        for kind, e0 in list(self.ops):      # (positions shift as ops are merged: an op is found again by identity)
+            e = e0
             if kind not in ("focus_conv", "rgb_conv") or e["pc"].Cout != 32:
                 continue
             rgb = kind == "rgb_conv"
@@ -618,8 +620,9 @@ class Graph:
                 npc = PackedConv(w16.reshape(rows, 160).contiguous(), b16, 16, 32, 3, 3, 160, rows, cin_real=3)
                 self.keep.append(npc)
                 e = dict(e, pc=npc)
-            j = next(i for i, (_, r) in enumerate(self.ops) if r is B)
+            idx = next(i for i, (_, r) in enumerate(self.ops) if r is e0)
             self.ops[idx] = ("focus_pair", dict(focus=e, conv=B, rgb=rgb))
+            j = next(i for i, (_, r) in enumerate(self.ops) if r is B)
             root.dead = True          # never written, never read: no memory behind it
             del self.ops[j]
             self.ext_in = [i - 1 if i > j else i for i in self.ext_in]
@@ -669,8 +672,21 @@ class Plan:
         self.splitk_ws = []
         if _split_k and g.device != "cpu" and torch.device(g.device).type == "cuda":
             lib = _ffi.lib()
+            def ws_bytes(op):
+                # (a caller-owned input / output / residual is patched in per call and still null here: the sizing query
+                # only validates pointers, so a stand-in address goes in for its duration)
+                d = op.conv
+                saved = (d.x, d.y, d.res)
+                probe = 256
+                d.x, d.y = d.x or probe, d.y or probe
+                if d.res_mode != _ffi.RES_NONE:
+                    d.res = d.res or probe
+                n = int(lib.ydet_conv_splitk_workspace_bytes(C.byref(d)))
+                d.x, d.y, d.res = saved
+                return n
+
             for ops in self.op_lists:
-                need = [int(lib.ydet_conv_splitk_workspace_bytes(C.byref(op.conv))) if op.kind == _ffi.OP_CONV else 0 for op in ops]
+                need = [ws_bytes(op) if op.kind == _ffi.OP_CONV else 0 for op in ops]
                 ws = torch.empty(max(need), dtype=torch.uint8, device=g.device) if max(need, default=0) > 0 else None
                 self.splitk_ws.append(ws)
                 for op, nb in zip(ops, need):
@@ -896,12 +912,14 @@ class Plan:
                 _ffi.check(lib.ydet_run_ops(self.ops, len(self.ops), _ffi.current_stream()), "ydet_run_ops")
             else:
                 _ffi.check(lib.ydet_run_op_lists(self._lists, self._counts, R, _ffi.current_stream()), "ydet_run_op_lists")
+        # Every tensor handed back is the caller's: external storages are allocated per call above, and an output that
+        # lives in the plan's activation arena (which the next run on this plan overwrites) is copied out.
         for name, t in self.g.outputs.items():
             root, off = t.resolve()
             if root.external:
                 outs[name] = ext[root][..., off:off + t.C]
             elif R == 1:
-                outs[name] = self.arenas[0][root][..., off:off + t.C]
+                outs[name] = self.arenas[0][root][..., off:off + t.C].clone()
             else:
                 outs[name] = torch.cat([ar[root][..., off:off + t.C] for ar in self.arenas], 0)
         return outs

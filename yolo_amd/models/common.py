@@ -54,6 +54,16 @@ class SPP(_m.SPP):
         _rebuild(self, ("cv1", "cv2"))
 
 
+class C3SPP(C3):
+    """Reference yolov5_official/modules.py:262-268 (the compat file has no C3SPP of its own; offered here with the compat
+    activation for checkpoints that pickle it under this path)."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13), n=1, shortcut=True, g=1, e=0.5):
+        super().__init__(c1, c2, n=n, shortcut=shortcut, g=g, e=e)
+        c_ = int(c2 * e)
+        self.m = SPP(c_, c_, k)
+
+
 class Focus(_m.Focus):
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
         super().__init__(c1, c2, k, s, p, g, act)

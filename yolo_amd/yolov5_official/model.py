@@ -18,7 +18,7 @@ import torch.nn.functional as F
 import yaml
 
 from .. import _ffi, engine, ops
-from .modules import C3, SPP, Bottleneck, BottleneckCSP, Concat, Contract, Conv, DWConv, Expand, Focus, activation_code
+from .modules import C3, C3SPP, SPP, Bottleneck, BottleneckCSP, Concat, Contract, Conv, DWConv, Expand, Focus, activation_code
 
 DEFAULT_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yamls", "yolov5s.yaml")
 
@@ -154,10 +154,10 @@ class Detect(nn.Module):
 
 _MODULES = {
     "Conv": Conv, "Bottleneck": Bottleneck, "SPP": SPP, "DWConv": DWConv, "Focus": Focus,
-    "BottleneckCSP": BottleneckCSP, "C3": C3, "Concat": Concat, "Contract": Contract, "Expand": Expand,
+    "BottleneckCSP": BottleneckCSP, "C3": C3, "C3SPP": C3SPP, "Concat": Concat, "Contract": Contract, "Expand": Expand,
     "Detect": Detect, "nn.Upsample": nn.Upsample, "nn.BatchNorm2d": nn.BatchNorm2d,
 }
-_CHANNEL_SCALED = (Conv, Bottleneck, SPP, Focus, BottleneckCSP, C3)
+_CHANNEL_SCALED = (Conv, Bottleneck, SPP, Focus, BottleneckCSP, C3)   # (the reference's list at :505 leaves C3SPP out too)
 _REPEAT_INSIDE = (BottleneckCSP, C3)
 
 

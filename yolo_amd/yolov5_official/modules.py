@@ -142,7 +142,8 @@ class C3(nn.Module):
     def lower(self, g, x):
         c_ = self.cv1.conv.out_channels
         a1, a2 = activation_code(self.cv1.act), activation_code(self.cv2.act)
-        if a1 == a2 and c_ % g.vec == 0 and all(isinstance(b, Bottleneck) and b.cv2.conv.out_channels == c_ for b in self.m):
+        chain = isinstance(self.m, nn.Sequential)      # (C3SPP puts a single SPP block there)
+        if chain and a1 == a2 and c_ % g.vec == 0 and all(isinstance(b, Bottleneck) and b.cv2.conv.out_channels == c_ for b in self.m):
             # cv1 and cv2 read the same input: one convolution writes [cv1(x) | cv2(x)] straight into the concat buffer;
             # the bottleneck chain then updates the first half in place (its residual is read by the thread that
             # overwrites it), so the concat never exists as an operation.
@@ -166,7 +167,7 @@ class C3(nn.Module):
             for b in self.m:
                 b.lower(g, y, out=y)
             return self.cv3.lower(g, cat)
-        y1 = _lower_chain(g, self.m, self.cv1.lower(g, x))
+        y1 = _lower_chain(g, self.m if chain else [self.m], self.cv1.lower(g, x))
         y2 = self.cv2.lower(g, x)
         return self.cv3.lower(g, g.cat([y1, y2]))
 
@@ -190,6 +191,15 @@ class SPP(nn.Module):
         if ks != (5, 9, 13):
             raise NotImplementedError(f"SPP kernels {ks}: the fused pooling kernel implements (5, 9, 13)")
         return self.cv2.lower(g, g.spp(self.cv1.lower(g, x)))
+
+
+class C3SPP(C3):
+    """C3 whose middle is one SPP block instead of the bottleneck chain (reference :262-268)."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13), n=1, shortcut=True, g=1, e=0.5):
+        super().__init__(c1, c2, n=n, shortcut=shortcut, g=g, e=e)
+        c_ = int(c2 * e)
+        self.m = SPP(c_, c_, k)
 
 
 class Focus(nn.Module):

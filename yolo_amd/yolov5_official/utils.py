@@ -10,6 +10,9 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+# numpy greedy NMS of one class (reference :551-578): line for line the function of utils/utils.py:15-42 -- 1e-28 floor on the
+# intersection sides, survivors while ovr <= threshold -- so the two import names share the GPU-backed implementation
+from ..utils.utils import nms  # noqa: F401
 
 
 # ---- box formats (reference :581-598) --------------------------------------------------------------

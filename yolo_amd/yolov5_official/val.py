@@ -4,9 +4,10 @@
 Differences in mechanism, not in results: forward, decode, NMS and the IoU matrices run on the GPU
 through libydet.so; detections stay in padded device tensors (`[bs, max_det, 6]` + counts) until they
 are needed on the host; when torch.distributed is initialised each rank evaluates one contiguous range of
-the images (distributed.shard_range; a dataloader over an indexable dataset is re-built over just that
-range, so a rank never loads an image it does not own) and the ranks exchange the padded detections
-with one all_gather_into_tensor, the (variable-length) labels with a second, before the AP computation.
+whole batches (distributed.shard_range; a dataloader that walks an indexable dataset in order is re-built over
+just that range, so a rank never loads an image it does not own; other iterables are drawn lazily up to the end
+of the range) and the ranks exchange the padded detections with one all_gather_into_tensor, the
+(variable-length) labels with a second, before the AP computation.
 """
 from pathlib import Path
 
@@ -28,30 +29,53 @@ def save_one_txt(predn, save_conf, shape, file):
 
 
 def _shard_batches(dataloader, rank, world):
-    """(iterable of batches, global index of its first image, images in the whole set or None, [lo, hi) owned here).
+    """-> (iterator of (global index of the batch's first image, batch) over the batches this rank owns,
+           images per rank as a list when every rank can compute it without an exchange, else None).
 
-    One process: the dataloader as it is.  Several: the images are split into contiguous ranges whose boundaries fall
-    between batches (distributed.shard_range over the batches).  A torch DataLoader over an indexable dataset is
-    re-built over just this rank's range; any other iterable of batches (a list, a generator) is walked and the
-    batches outside the range are skipped without being moved to the device."""
+    Ranks own contiguous ranges of whole batches (distributed.shard_range over the batch count).
+    * A torch DataLoader that walks an indexable dataset in order (sequential sampler, default batch sampler, no
+      drop_last) is re-built over just this rank's image range with the same batch size, collate function, workers and
+      worker initialiser: a rank never loads an image it does not own, and every rank knows every shard's size.
+    * Any other iterable with a length (a list of batches, a DataLoader with a sampler of its own) is walked lazily up to
+      the end of this rank's range; batches in front of the range are drawn and dropped without being moved to the device.
+    * An iterable without a length (a generator) has to be drawn completely first: its batch count is not known otherwise."""
+    def running(batches, base=0):
+        for b in batches:
+            yield base, b
+            base += b[0].shape[0]
+
     if world == 1:
-        return dataloader, 0, None, (0, float("inf"))
+        return running(dataloader), None
     ds, bs = getattr(dataloader, "dataset", None), getattr(dataloader, "batch_size", None)
-    if ds is not None and bs and hasattr(ds, "__len__") and hasattr(ds, "__getitem__"):
+    tud = torch.utils.data
+    in_order = (isinstance(dataloader, tud.DataLoader) and bs and hasattr(ds, "__len__") and hasattr(ds, "__getitem__")
+                and isinstance(dataloader.sampler, tud.SequentialSampler) and type(dataloader.batch_sampler) is tud.BatchSampler
+                and not dataloader.drop_last)
+    if in_order:
         n = len(ds)
         nbatch = (n + bs - 1) // bs
-        b0, b1 = ydist.shard_range(nbatch, rank, world)
-        lo, hi = b0 * bs, min(b1 * bs, n)
-        sub = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=bs, shuffle=False,
-                                          num_workers=getattr(dataloader, "num_workers", 0),
-                                          collate_fn=getattr(dataloader, "collate_fn", None),
-                                          pin_memory=getattr(dataloader, "pin_memory", False))
-        return sub, lo, None, (lo, hi)      # (shards of whole batches differ in size by up to a batch: sizes are exchanged)
-    batches = list(dataloader) if not isinstance(dataloader, (list, tuple)) else dataloader
-    sizes = [b[0].shape[0] for b in batches]
-    b0, b1 = ydist.shard_range(len(batches), rank, world)
-    lo, hi = sum(sizes[:b0]), sum(sizes[:b1])
-    return batches, 0, None, (lo, hi)
+        bounds = [ydist.shard_range(nbatch, r, world) for r in range(world)]
+        sizes = [min(b1 * bs, n) - min(b0 * bs, n) for b0, b1 in bounds]
+        lo = min(bounds[rank][0] * bs, n)
+        kw = dict(batch_size=bs, shuffle=False, num_workers=dataloader.num_workers, collate_fn=dataloader.collate_fn,
+                  pin_memory=dataloader.pin_memory, worker_init_fn=dataloader.worker_init_fn, timeout=dataloader.timeout)
+        if dataloader.num_workers > 0:
+            kw.update(persistent_workers=dataloader.persistent_workers, prefetch_factor=dataloader.prefetch_factor)
+        sub = tud.DataLoader(tud.Subset(ds, range(lo, lo + sizes[rank])), **kw)
+        return running(sub, lo), sizes
+    if not hasattr(dataloader, "__len__"):
+        dataloader = list(dataloader)
+    b0, b1 = ydist.shard_range(len(dataloader), rank, world)
+
+    def owned():
+        base = 0
+        for i, b in enumerate(dataloader):
+            if i >= b1:
+                break
+            if i >= b0:
+                yield base, b
+            base += b[0].shape[0]
+    return owned(), None
 
 
 @torch.no_grad()
@@ -88,54 +112,47 @@ def run(data,
     loss = torch.zeros(3, device=dev)
 
     dets, counts, ids, tgts = [], [], [], []   # this rank's padded detections / labels in native image space
-    seen_local = 0
-    batches, img_base, total, (lo, hi) = _shard_batches(dataloader, rank, world)
-    for batch_i, (img, targets, paths, shapes) in enumerate(batches):
+    batches, sizes = _shard_batches(dataloader, rank, world)
+    for img_base, (img, targets, paths, shapes) in batches:
         nb = img.shape[0]
-        mine = lo <= img_base and img_base + nb <= hi
-        if not mine and world > 1 and img_base < hi and img_base + nb > lo:
-            raise RuntimeError("a batch straddles two ranks' image ranges: shard boundaries must fall between batches")
-        if mine:
-            img = img.to(dev, non_blocking=True)
-            if not (img.dtype == torch.uint8 and img.is_cuda and not augment):
-                img = (img.half() if half else img.float()) / 255.0
-            # else: uint8 batches go to the model as they are; its first kernel applies the / 255 while loading
-            targets = targets.to(dev).clone()
-            _, _, height, width = img.shape
-            out, train_out = model(img, augment=augment)
-            if compute_loss:
-                loss += compute_loss([t.float() for t in train_out], targets)[1]
-            targets[:, 2:] *= torch.tensor([width, height, width, height], device=dev, dtype=targets.dtype)
-            lb = [targets[targets[:, 0] == i, 1:] for i in range(nb)] if save_hybrid else []
-            det, cnt = non_max_suppression_padded(out.float(), conf_thres, iou_thres, labels=lb, multi_label=True,
-                                                  agnostic=single_cls, max_det=max_det)
-            if single_cls:
-                det[..., 5] = 0
-            # native-space boxes: the per-image gain/pad differ, so the rescale is done per image on the device
+        img = img.to(dev, non_blocking=True)
+        if not (img.dtype == torch.uint8 and img.is_cuda and not augment):
+            img = (img.half() if half else img.float()) / 255.0
+        # else: uint8 batches go to the model as they are; its first kernel applies the / 255 while loading
+        targets = targets.to(dev).clone()
+        _, _, height, width = img.shape
+        out, train_out = model(img, augment=augment)
+        if compute_loss:
+            loss += compute_loss([t.float() for t in train_out], targets)[1]
+        targets[:, 2:] *= torch.tensor([width, height, width, height], device=dev, dtype=targets.dtype)
+        lb = [targets[targets[:, 0] == i, 1:] for i in range(nb)] if save_hybrid else []
+        det, cnt = non_max_suppression_padded(out.float(), conf_thres, iou_thres, labels=lb, multi_label=True,
+                                              agnostic=single_cls, max_det=max_det)
+        if single_cls:
+            det[..., 5] = 0
+        # native-space boxes: the per-image gain/pad differ, so the rescale is done per image on the device
+        for si in range(nb):
+            scale_coords(img[si].shape[1:], det[si, :, :4], shapes[si][0], shapes[si][1])
+        sel = targets.clone()
+        if len(sel):
+            box = xywh2xyxy(sel[:, 2:6])
             for si in range(nb):
-                scale_coords(img[si].shape[1:], det[si, :, :4], shapes[si][0], shapes[si][1])
-            sel = targets.clone()
-            if len(sel):
-                box = xywh2xyxy(sel[:, 2:6])
-                for si in range(nb):
-                    rows = sel[:, 0] == si
-                    if rows.any():
-                        b = box[rows]
-                        scale_coords(img[si].shape[1:], b, shapes[si][0], shapes[si][1])
-                        box[rows] = b
-                sel[:, 2:6] = box
-                sel[:, 0] += img_base
-            dets.append(det)
-            counts.append(cnt)
-            ids.append(torch.arange(img_base, img_base + nb, device=dev))
-            tgts.append(sel)
-            seen_local += nb
-            if save_txt:
-                c_host = cnt.tolist()
-                for si in range(nb):
-                    save_one_txt(det[si, :c_host[si]], save_conf, shapes[si][0],
-                                 file=str(save_dir) + "labels/" + Path(paths[si]).stem + ".txt")
-        img_base += nb
+                rows = sel[:, 0] == si
+                if rows.any():
+                    b = box[rows]
+                    scale_coords(img[si].shape[1:], b, shapes[si][0], shapes[si][1])
+                    box[rows] = b
+            sel[:, 2:6] = box
+            sel[:, 0] += img_base
+        dets.append(det)
+        counts.append(cnt)
+        ids.append(torch.arange(img_base, img_base + nb, device=dev))
+        tgts.append(sel)
+        if save_txt:
+            c_host = cnt.tolist()
+            for si in range(nb):
+                save_one_txt(det[si, :c_host[si]], save_conf, shapes[si][0],
+                             file=str(save_dir) + "labels/" + Path(paths[si]).stem + ".txt")
 
     def _cat(xs, shape, dtype):
         return torch.cat(xs, 0) if xs else torch.zeros(shape, device=dev, dtype=dtype)
@@ -145,7 +162,8 @@ def run(data,
     iid = _cat(ids, (0,), torch.int64)
     tgt = _cat(tgts, (0, 6), torch.float32).float()
     # the one exchange step: padded detections + labels of every shard
-    det, cnt, iid = ydist.all_gather_detections(det, cnt, iid, total=total)
+    # (shard sizes known to every rank: no size exchange and no host synchronisation in front of the collective)
+    det, cnt, iid = ydist.all_gather_detections(det, cnt, iid, sizes=sizes)
     tgt = ydist.all_gather_rows(tgt)
 
     stats = []
