@@ -566,11 +566,14 @@ def test_conv_pw_streaming_equals_tiled(geom):
         assert torch.equal(one[0], full[n]), f"image {n}"
 
 
-@pytest.mark.parametrize("geom", [(32, 40, 40, 128, 512, 3, 1, True), (31, 41, 39, 64, 400, 3, 1, False), (30, 44, 44, 512, 256, 1, 1, False)])
+@pytest.mark.parametrize("geom", [(32, 40, 40, 128, 512, 3, 1, True), (31, 41, 39, 64, 400, 3, 1, False), (30, 44, 44, 512, 256, 1, 1, False),
+                                  (32, 40, 40, 96, 256, 3, 1, False), (32, 80, 80, 128, 256, 3, 2, False), (25, 38, 38, 256, 512, 3, 1, True)])
 def test_conv_256_tile_equals_small_launch(geom):
-    """Wide layers with a long K and about a tile per CU take the 256 x 256 sixteen-wave tile; one image of the same layer
-    takes a 128-wide tile.  Same MFMA, same K order, same epilogue: every image equals its own single-image run bit for
-    bit (ragged channel tile: 400 = 256 + 144; ragged pixel tiles; residual)."""
+    """Wide layers with a long K and about a tile per CU take the 256 x 256 tile -- eight waves with the software-pipelined
+    K loop and buffer-addressed operands (padding taps and rows beyond the last pixel are out-of-range offsets that read
+    zeros) where Cin is a multiple of 64, sixteen waves otherwise (Cin = 96 here); one image of the same layer takes a
+    128-wide tile.  Same MFMA, same K order, same epilogue: every image equals its own single-image run bit for bit
+    (ragged channel tile: 400 = 256 + 144; ragged pixel tiles; residual; stride 2; K = 2304)."""
     N, H, W, cin, cout, k, s, res = geom
     gen = _gen(43, f"t256{geom}")
     p = k // 2

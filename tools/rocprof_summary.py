@@ -37,7 +37,9 @@ def label_of(name):
         nums = re.findall(r"Li(\d+)E", name) or re.findall(r"(?<![\w.])(\d+)(?=[,>])", name)
         bn, bm = nums[0], nums[1]
         if kind == "dma":
-            if re.search(r"Li\d+ELb1E|, true(, \d+, \d+)?>", name):      # HEAD = true: the prediction conv with the decode epilogue
+            # template arguments: <TIN, TOUT, BN, BM, WARPS_N, WARPS_M, HEAD, KCH, NST, PIPE>: HEAD is the first bool
+            m5 = re.search(r"(?:Li\d+E){4}Lb([01])E", name) or re.search(r"(?:\d+, ){4}(true|false)", name)
+            if m5 and m5.group(1) in ("1", "true"):      # the prediction conv with the decode epilogue
                 return "conv_head_decode"
             return f"conv_dma<{bn}x{bm},{dts}>"
         one = "Lb1E" in name or re.search(r"true>", name)

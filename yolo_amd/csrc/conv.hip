@@ -30,6 +30,7 @@
 //                       registers -> LDS, two stages.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -239,14 +240,16 @@ __device__ unsigned long long g_trace[64 * 32];
 
 // Waves per SIMD the register allocation must leave room for: the eight-wave tile runs two workgroups per CU (its
 // LDS ring allows exactly two), the 128 x 128 four-wave tile three.
-constexpr int conv_dma_min_waves(int bn, int bm, int nw, bool head) {
+constexpr int conv_dma_min_waves(int bn, int bm, int nw, bool head, bool pipe = false) {
+    if (pipe) return 2;      // (a wave of the pipelined form holds a 128 x 64 accumulator and two sets of operand fragments)
     return head ? (nw == 8 ? 4 : 1) : nw == 8 ? 4 : (nw == 4 && bn == 128 && bm == 128) ? 3 : 1;
 }
 
 // KCH: 16-byte chunks per LDS row = K extent of a ring stage (4: 64-byte rows, 32 bf16 of K per step; 8: 128-byte rows,
 // two MFMA K-substeps per step, every LDS-DMA instruction fetches whole 128-byte lines).  NST: stages of the ring.
-template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool HEAD = false, int KCH = 4, int NST = 3>
-__global__ __launch_bounds__(64 * WARPS_N * WARPS_M, conv_dma_min_waves(BN, BM, WARPS_N * WARPS_M, HEAD))
+// PIPE: the K loop is software-pipelined over MFMA sub-steps (see below).
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, bool HEAD = false, int KCH = 4, int NST = 3, bool PIPE = false>
+__global__ __launch_bounds__(64 * WARPS_N * WARPS_M, conv_dma_min_waves(BN, BM, WARPS_N * WARPS_M, HEAD, PIPE))
 void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     constexpr int NW = WARPS_N * WARPS_M;         // waves per workgroup (4 or 8)
     constexpr int NT = 64 * NW;
@@ -417,8 +420,57 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
         tapoff = ((long long)(kh * a.W + kw) * a.x_ld + c0) * (long long)sizeof(TIN);
     }
 
+    // Pipelined form: both operands are addressed through buffer descriptors with 32-bit offsets (a third of the address
+    // registers of the pointer form), and a padding tap is an offset beyond the descriptor's extent, which the hardware
+    // answers with zeros.  A weight row group j of a wave differs from group 0 by a wave-uniform number of rows (see the
+    // permutation above), so one lane offset serves all groups and the rest rides in the scalar offset.
+    unsigned xoff[PIPE ? XJ : 1] = {};
+    unsigned woff_lane = 0, wuni[PIPE ? WJ : 1] = {};
+    const char* xb = a.x + (size_t)a.x_coff * sizeof(TIN);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)(unsigned)a.x_span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.w), 0, (int)(unsigned)a.w_span, 0x00020000);
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) xoff[j] = (unsigned)(unsigned long long)(xsrc[j] - xb);
+        const int r = RPI == 16 ? srow : (wave & 1) * 8 + srow;                  // row inside its group of sixteen
+        const int lrow = PERM ? 8 * (r >> 2) + (r & 3) : r;
+        woff_lane = (unsigned)(((n0 + lrow) * a.kp + lchunk * EPC) * (int)sizeof(TIN));
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int g = RPI == 16 ? j * NW + wave : (j * NW + wave) >> 1;      // group of sixteen rows
+            const int urow = PERM ? (g / FN) * WN + 32 * ((g % FN) >> 1) + 4 * ((g % FN) & 1) : 16 * g;
+            wuni[j] = (unsigned)(urow * a.kp * (int)sizeof(TIN));
+        }
+    }
     auto issue = [&](int stage) {
         char* dst = smem + stage * STAGE + wave * 1024;
+        if constexpr (PIPE) {
+            const unsigned ws = (unsigned)wbase + (unsigned)ktile * (unsigned)(BK * sizeof(TIN));
+#pragma unroll
+            for (int j = 0; j < WJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(dst + j * (NW * 1024)), 16,
+                                                         (int)woff_lane, (int)(ws + wuni[j]), 0, 0);
+            const unsigned toff = (unsigned)tapoff;
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const bool ok = (xmask[j] >> tap) & 1u;
+                const unsigned voff = ok ? xoff[j] + toff : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(dst + WROWS * RB + j * (NW * 1024)),
+                                                         16, (int)voff, 0, 0, 0);
+            }
+            // (the walk over taps without branches: the issue sits in the middle of a block of MFMAs)
+            ++ktile;
+            c0 += BK;
+            const int wrap = c0 == a.Cin ? 1 : 0;
+            c0 = wrap ? 0 : c0;
+            tap += wrap;
+            kw += wrap;
+            const int wrap2 = kw == a.KW ? 1 : 0;
+            kw = wrap2 ? 0 : kw;
+            kh += wrap2;
+            tapoff = (long long)(unsigned)(((kh * a.W + kw) * a.x_ld + c0) * (int)sizeof(TIN));
+            return;
+        }
         const long long woff = wbase + (long long)ktile * BK * (long long)sizeof(TIN);
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
@@ -472,6 +524,89 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
     }
 
     YDET_STAMP(1);
+    if constexpr (PIPE) {
+        // Software-pipelined K loop.  The operand fragments of MFMA sub-step u + 1 are fetched from LDS while the MFMAs of
+        // sub-step u run out of registers (two fragment sets, used alternately), so the matrix pipe never waits for an LDS
+        // round trip behind a barrier.  The registers act as one more ring stage: once every wave holds the last fragments
+        // of tile kt, that tile's LDS stage is refilled with tile kt + NST.  One barrier per tile, in front of its last
+        // sub-step: by then every wave has (1) waited for its own LDS-DMA pieces of tile kt + 1 and (2) received the last
+        // fragments of tile kt.  Sums are accumulated in the same order as in the plain loop: results are bit-identical.
+        // (Built for 128-byte rows -- two sub-steps per tile -- and a two-stage ring.  The 64-byte-row form with four
+        // waves per 128 x 256 tile was measured level with the plain eight-wave tile on layers of 128 output channels:
+        // those are bound by the operand traffic of their narrow tile, not by the loop.)
+        static_assert(!HEAD && NST == 2 && KSUB == 2, "pipelined loop: 128-byte rows, two stages");
+        frag_t fa[2][FN], fb[2][FM];
+        auto read_frags = [&](int stage, int kk, frag_t (&A)[FN], frag_t (&B)[FM]) {
+            const char* ws = smem + stage * STAGE + (wn * WN) * RB + fr_off[kk];
+            const char* xs = smem + stage * STAGE + WROWS * RB + (wm * WM) * RB + fr_off[kk];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) A[i] = *reinterpret_cast<const frag_t*>(ws + i * 16 * RB);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) B[j] = *reinterpret_cast<const frag_t*>(xs + j * 16 * RB);
+        };
+#pragma unroll
+        for (int p = 0; p < NST; ++p)
+            if (p < nk) issue(p);
+        if (nk >= NST) wait_vmcnt<(NST - 1) * LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(0, 0, fa[0], fb[0]);
+        int st_cur = 0;
+        // one sub-step: P = which fragment set holds it; MORE = a sub-step follows (known at compile time, so that the
+        // fragment reads and the MFMAs sit in ONE basic block and can be interleaved: the last tile is peeled off the loop)
+        // ISSUE: the block starts with the refill of the stage just vacated (tile kt + NST); the tiles that no longer
+        // refill are peeled off the loop as well, so the refill needs no branch.
+        auto substep = [&](auto par, auto more, auto refill, int kt, int kk) {
+            constexpr int P = decltype(par)::value;
+            constexpr bool MORE = decltype(more)::value;
+            constexpr bool ISSUE = decltype(refill)::value;
+            const bool last_sub = kk == KSUB - 1;
+            const int st_next = st_cur + 1 == NST ? 0 : st_cur + 1;
+            if (last_sub) {
+                wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (ISSUE) issue(st_cur);
+            }
+            if constexpr (MORE) read_frags(last_sub ? st_next : st_cur, last_sub ? 0 : kk + 1, fa[P ^ 1], fb[P ^ 1]);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = mma(fa[P][i], fb[P][j], acc[i][j]);
+            // order inside the block: the first MFMA (its operands arrived a sub-step ago) leads, then one fragment read per
+            // two MFMAs -- no read is waited for before the next sub-step.  (The LDS-DMA instructions of a refill stay in
+            // front of the block: spread between the MFMAs they measured 1 % slower.)
+            if constexpr (MORE) {
+                if constexpr (ISSUE) __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                for (int r = 0; r < FN + FM; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+            }
+            if (last_sub) st_cur = st_next;
+        };
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 1> P1{};
+        constexpr std::true_type Y{};
+        constexpr std::false_type N{};
+        {
+            int kt = 0;
+            for (; kt + NST < nk; ++kt) {       // tiles whose stage is refilled
+                substep(P0, Y, N, kt, 0);
+                substep(P1, Y, Y, kt, 1);
+            }
+            for (; kt + 1 < nk; ++kt) {
+                substep(P0, Y, N, kt, 0);
+                substep(P1, Y, N, kt, 1);
+            }
+            substep(P0, Y, N, nk - 1, 0);
+            substep(P1, N, N, nk - 1, 1);
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
         if (p < nk) issue(p);
@@ -506,6 +641,8 @@ void conv_dma_kernel(const ConvArgs a, const HeadArgs h) {
             for (int i = 0; i < FN; ++i)
 #pragma unroll
                 for (int j = 0; j < FM; ++j) acc[i][j] = mma(fa[kk][i], fb[kk][j], acc[i][j]);
+    }
+
     }
 
     // ---- optional 1x1 follower on the tile in registers ------------------------------------------------------
@@ -895,7 +1032,7 @@ int launch_direct(const ConvArgs& a, hipStream_t stream) {
     return YDET_OK;
 }
 
-template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, int KCH = 4, int NST = 3>
+template <typename TIN, typename TOUT, int BN, int BM, int WARPS_N, int WARPS_M, int KCH = 4, int NST = 3, bool PIPE = false>
 int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_n = (a.Cout + BN - 1) / BN;
@@ -924,11 +1061,11 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
         if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation and device
             static unsigned char optin[kMaxDevices];
             const int rc = raise_dynamic_lds_limit(
-                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST>), (int)lds_dma, optin, "conv");
+                reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST, PIPE>), (int)lds_dma, optin, "conv");
             if (rc != YDET_OK) return rc;
         }
         if (a.y2 && !a.lds_epilogue) return fail(YDET_ERR_ARG, "conv: a second destination needs 16-byte aligned output slices");
-        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST>), dim3((unsigned)nblk),
+        hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST, PIPE>), dim3((unsigned)nblk),
                            dim3(64 * NW), lds_dma, stream, a, HeadArgs{});
         YDET_CHECK_LAUNCH("conv_dma_kernel");
         return YDET_OK;
@@ -936,7 +1073,7 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     if (a.y2) return fail(YDET_ERR_ARG, "conv: a second destination needs Cin to be a multiple of %d and at least 64 output channels", BK);
     if (a.pw_w) return fail(YDET_ERR_ARG, "conv: a 1x1 follower needs the LDS-DMA kernel");
     if (a.x_up) return fail(YDET_ERR_ARG, "conv: an upsampled source needs the LDS-DMA kernel (Cin a multiple of %d, more than 32 output channels)", BK);
-    if constexpr (WARPS_N * WARPS_M != 4 || KCH != 4) {
+    if constexpr (WARPS_N * WARPS_M != 4 || KCH != 4 || PIPE) {
         return fail(YDET_ERR_ARG, "conv: the %dx%d tile needs Cin to be a multiple of %d", BN, BM, BK);
     } else {
         const size_t lds = 2 * (size_t)(BN + BM) * 64;
@@ -969,6 +1106,11 @@ static bool wide_tile_pays(long long M, int Cout, int K, bool dma_ok) {
     return r256 * gain < r128 - 0.02;
 }
 
+// The pipelined tiles address their operands with 32-bit offsets and have no path for an upsampled source or a K split.
+static bool pipe_ok(const ConvArgs& a) {
+    return a.x_span > 0 && a.x_span < 0xFFFFFFF0LL && a.w_span < 0x7FFFFFFFLL && a.up_C == 0 && a.splits <= 1 && a.pw_w == nullptr;
+}
+
 template <typename TIN, typename TOUT>
 int launch_dtype(const ConvArgs& a, hipStream_t stream) {
     if (a.groups > 1 || a.dilation > 1) return launch_direct<TIN, TOUT>(a, stream);
@@ -978,6 +1120,10 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
         int bn = 0, bm = 0, kch = 4, nst = 3;
         const int got = sscanf(forced, "%dx%dk%ds%d", &bn, &bm, &kch, &nst);
         if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
+            // 256x256p: the software-pipelined form (eight waves of 128 x 64, 128-byte rows, two stages, Cin a multiple of 64)
+            if (got == 2 && strchr(forced, 'p') && a.KH * a.KW <= 32 && pipe_ok(a)) {
+                if (bn == 256 && bm == 256 && a.Cin % 64 == 0 && a.Cout > 128) return launch_tile<TIN, TOUT, 256, 256, 2, 4, 8, 2, true>(a, stream);
+            }
             // <channels>x<pixels>k8s<stages>: the 128-byte-row variants (where Cin is a multiple of 64; other layers
             // keep the default choice)
             if (got == 4 && kch == 8 && a.Cin % 64 == 0 && a.KH * a.KW <= 32 && a.Cout > 64) {
@@ -1014,8 +1160,14 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
         const int rem256 = a.Cout % 256;
         const long long tiles256 = (a.M + 255) / 256 * ((a.Cout + 255) / 256);
         if (t256_on && a.Cout >= 256 && (rem256 == 0 || rem256 > 128) && a.Cin % 32 == 0 && a.KH * a.KW <= 32 &&
-            a.KH * a.KW * a.Cin >= 512 && tiles256 >= 192 && a.splits <= 1)
+            a.KH * a.KW * a.Cin >= 512 && tiles256 >= 192 && a.splits <= 1) {
+            // ... as eight waves of 128 x 64 with the software-pipelined K loop where the shape allows it (128-byte rows:
+            // Cin a multiple of 64; operands within 4 GB): bit-identical, 6-15 % faster on MI355X (3x3 256 -> 512 at 38 x 38
+            // 215 -> 191 us = 1.14 PFLOP/s, 3x3 512 -> 1024 at 19 x 19 238 -> 207 us, 3x3 128 -> 256 at 76 x 76 272 -> 256 us)
+            static const bool pipe_on = !(getenv("YDET_CONV_PIPE") && atoi(getenv("YDET_CONV_PIPE")) == 0);
+            if (pipe_on && a.Cin % 64 == 0 && pipe_ok(a)) return launch_tile<TIN, TOUT, 256, 256, 2, 4, 8, 2, true>(a, stream);
             return launch_tile<TIN, TOUT, 256, 256, 4, 4>(a, stream);
+        }
         // Few tiles and a long K: the launch is one or two rounds of workgroups whose time is the K loop's, and the
         // 128-byte-row variant walks K in half as many steps (half the barriers and waits; two stages of twice the
         // size).  With many tiles per CU the three-stage ring at three workgroups per CU hides more (measured).
@@ -1125,6 +1277,8 @@ static int fill_conv_args(const ydet_conv_desc* d, ConvArgs& a) {
     }
     a.groups = groups; a.dilation = dil; a.cin_group = cin_group;
     a.splits = 0; a.tiles_per_split = 0; a.split_taps = 0; a.split_cin = 0; a.split_stride = 0;
+    a.x_span = ((long long)d->N * d->H * d->W * d->x_ld - d->x_coff) * (long long)dtype_size(d->in_dtype);
+    a.w_span = (long long)d->cout_pad * d->kp * (long long)dtype_size(d->in_dtype);
     a.x_up = nullptr; a.up_ld = 0; a.up_coff = 0; a.up_C = 0;
     if (d->x_up) {
         YDET_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H % 2 == 0 && d->W % 2 == 0,

@@ -43,6 +43,10 @@ struct ConvArgs {
     // convolution, and writes its fp32 partial sums at y + s * split_stride.  splits <= 1: the whole K, as ever.
     int splits, tiles_per_split, split_taps, split_cin;
     long long split_stride;
+    // bytes from the first byte of the input slice (x + x_coff) to the end of the tensor, and of the packed weights: the
+    // extents of the buffer descriptors the pipelined kernel addresses them through (32-bit offsets; an offset beyond the
+    // extent reads zeros, which is how padding taps are fetched)
+    long long x_span, w_span;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

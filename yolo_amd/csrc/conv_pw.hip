@@ -114,7 +114,14 @@ __global__ __launch_bounds__(64 * PW_NW, MINW) void conv_pw_kernel(const ConvArg
                 pu = a.x_up + (pix * a.up_ld + a.up_coff + q * 8) * 2;
             }
 #pragma unroll
-            for (int s = 0; s < NK; ++s) b[j][s] = *reinterpret_cast<const bf16x8*>((UP && s < nk_up ? pu : p) + s * 64);
+            for (int s = 0; s < NK; ++s) {
+                const bf16x8* src = reinterpret_cast<const bf16x8*>((UP && s < nk_up ? pu : p) + s * 64);
+#if defined(YDET_PW_NT) && YDET_PW_NT
+                b[j][s] = __builtin_nontemporal_load(src);
+#else
+                b[j][s] = *src;
+#endif
+            }
         }
     };
 
