@@ -596,27 +596,34 @@ def other_configs(dev, args, rank, world):
         m.clear()
         engine.set_compute_dtype(args.compute)
         torch.cuda.empty_cache()
-    for name, tag, size, batch, steps in (("C1", "v3tiny", 416, 1, 50), ("C2", "v2d19", 416, 32, 10), ("C3", "v3spp", 608, 64, 5),
-                                          ("C4", "v4", 608, 64, 5)):
+    for name, tag, size, batch, steps in (("C1", "v3tiny", 416, 1, 50), ("C2", "v2d19", 416, 32, 12), ("C3", "v3spp", 608, 64, 6),
+                                          ("C4", "v4", 608, 64, 6)):
         net = build_family_a(tag, size).to(dev)
         x = images(batch, size, seed=1, kind="randn").to(dev)
         # a single image leaves the deepest layers a handful of tiles each: their K is split over workgroups (opt-in: the
         # order of the fp32 sums then depends on the launch shape)
         engine.set_split_k(batch == 1)
         step_fn = net.detect_batch
+        # Batches are issued round-robin on HIP streams like the headline's (each stream has its own plan and activation
+        # arena): the per-class NMS of one batch (vector ALU work on a few workgroups) runs under the next batch's
+        # convolutions.  A single image (C1) is a latency measurement: one stream.
+        S = 1 if batch == 1 else max(1, min(args.streams, 2))
+        streams = [torch.cuda.Stream(dev) for _ in range(S)]
         with torch.no_grad():
-            for _ in range(2):
-                step_fn(x)
+            for k in range(2 * S):
+                with torch.cuda.stream(streams[k % S]):
+                    step_fn(x)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                step_fn(x)
+            for k in range(steps):
+                with torch.cuda.stream(streams[k % S]):
+                    step_fn(x)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
         engine.set_split_k(False)
         tf = FA_GFLOP[tag] * batch / dt / 1e3
         out[name] = {"workload": f"{tag} {size}x{size} batch {batch}, forward + decode + per-class NMS", "images_per_s": round(batch / dt, 1),
-                     "ms_per_step": round(dt * 1e3, 3), "steps": steps, "dtype": args.compute, "split_k": batch == 1,
+                     "ms_per_step": round(dt * 1e3, 3), "steps": steps, "streams": S, "dtype": args.compute, "split_k": batch == 1,
                      "conv_tflops_whole_step": round(tf, 1), "mfma_util_frac_whole_step": round(tf / PEAK_TFLOPS[args.compute], 4)}
         if name == "C1" and not args.no_cpu:
             out[name]["cpu_baseline"] = cpu_baseline_c1(net, x.cpu())

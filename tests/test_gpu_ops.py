@@ -600,6 +600,39 @@ def test_conv_256_tile_equals_small_launch(geom):
         assert torch.equal(one[0], full[n]), f"image {n}"
 
 
+@pytest.mark.parametrize("geom", [(64, 40, 40, 128, 128, "silu", "after"), (40, 37, 53, 128, 200, "silu", None), (33, 76, 76, 64, 96, "leaky", "after"),
+                                  (3, 152, 152, 64, 128, "silu", None), (2, 130, 224, 64, 128, "leaky", None), (36, 23, 40, 128, 256, "silu", "before")])
+def test_conv_patch_equals_tiled_launch(geom):
+    """3x3 / stride 1 / pad 1 layers over 64 or 128 channels with a tile of whole rows per CU take the kernel that holds the
+    rows' input patch in LDS (persistent workgroups: the next tile's patch and the residual pieces arrive under the K loop);
+    one image of the same layer has too few tiles and takes the tiled kernel.  Same MFMA, same K order, same epilogue:
+    every image equals its own single-image run bit for bit (ragged last row tile: 37 = 9 x 4 + 1 and 23 = 4 x 5 + 3; ragged
+    channel tile: 200 = 128 + 72, 96; the widest map the kernel takes; residual after and before the activation)."""
+    N, H, W, cin, cout, act, res = geom
+    gen = _gen(47, f"patch{geom}")
+    x = torch.randn(N, cin, H, W, generator=gen).bfloat16().float()
+    r = torch.randn(N, cout, H, W, generator=gen).bfloat16().float() if res else None
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).requires_grad_(False)
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (cin * 9)) ** 0.5)
+    conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    assert engine.conv_kernel_label(cin, cout, 3, 3, 1, _ffi.BF16, _ffi.BF16, M=N * H * W, res=res is not None,
+                                    geom=(N, H, W)) == f"conv_patch<c{cin}>"
+    assert engine.conv_kernel_label(cin, cout, 3, 3, 1, _ffi.BF16, _ffi.BF16, M=H * W, res=res is not None,
+                                    geom=(1, H, W)).startswith("conv_dma<")
+
+    def build(gr, ins):
+        kw = dict(res=ins[1], res_mode=_ffi.RES_AFTER_ACT if res == "after" else _ffi.RES_BEFORE_ACT) if res else {}
+        gr.to_nchw(gr.conv(ins[0], conv, act=_ffi.ACT_SILU if act == "silu" else _ffi.ACT_LEAKY, slope=0.1, **kw), "y")
+
+    full = _run_graph(build, *([x, r] if res else [x]), compute="bf16")["y"].float().cpu()
+    f = F.silu if act == "silu" else (lambda t: F.leaky_relu(t, 0.1))
+    ref = f(conv(x) + r) if res == "before" else f(conv(x)) + (r if res else 0)
+    assert rel_err(full.numpy(), ref.numpy()) < 2e-2
+    for n in (0, N // 2, N - 1):
+        one = _run_graph(build, *([x[n:n + 1], r[n:n + 1]] if res else [x[n:n + 1]]), compute="bf16")["y"].float().cpu()
+        assert torch.equal(one[0], full[n]), f"image {n}"
+
+
 GROUPED_CASES = [
     # N, H, W, Cin, Cout, k, s, p, groups, dilation, act, residual
     (2, 20, 20, 64, 64, 3, 1, 1, 64, 1, "silu", None),       # depthwise (DWConv, yolov5_official/modules.py:19-21)

@@ -152,6 +152,16 @@ def main():
                           "   | since start: loop begins, loop ends, epilogue ends, stores acked (cycles); whole (10 ns ticks): " +
                           " ".join(f"{buf[64 + w * 8 + i]:7d}" for i in range(5)) +
                           f" | A split: reads issued {buf[64 + w * 8 + 5]}, refill issued {buf[64 + w * 8 + 6]} | prologue: set-up done {buf[w * 8 + 7] >> 32}, first steps issued {buf[w * 8 + 7] & 0xffffffff}")
+        for li, (name, h) in enumerate(libs):
+            if hasattr(h, "ydet_debug_patch_trace"):
+                buf = (C.c_ulonglong * 128)()
+                torch.cuda.synchronize()
+                h.ydet_debug_patch_trace(buf)
+                print(f"   [{name}] workgroup 0, first tile, cycles per wave: K loop = work + waits for the ring + barriers | "
+                      "K loop, wait for next patch, patch to LDS, epilogue, barrier")
+                for w in range(8):
+                    b = buf[w * 16:w * 16 + 8]
+                    print(f"     wave {w}: {b[0]:7d} {b[1]:7d} {b[2]:7d} | " + " ".join(f"{v:7d}" for v in b[3:8]))
     print("total (median us)".ljust(38) + "".join(f"{t:26.1f}" for t in tot))
 
 

@@ -25,6 +25,9 @@ def label_of(name):
     m = re.search(r"conv_pw_kernel(?:ILi|<)(\d+)", name)      # first template argument: K steps of 32 channels
     if m:
         return f"conv_pw<k{32 * int(m.group(1))}>"
+    m = re.search(r"conv_patch_kernel(?:ILi|<)(\d+)", name)   # first template argument: input channels
+    if m:
+        return f"conv_patch<c{m.group(1)}>"
     m = re.search(r"conv_(dma|generic)_kernel", name)
     if m:
         kind = m.group(1)

@@ -1146,6 +1146,7 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
     }
     if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
         if (conv_pw_takes(a)) return launch_conv_pw(a, stream);
+        if (conv_patch_takes(a)) return launch_conv_patch(a, stream);
     }
     if (a.Cout <= 32) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
     if (a.Cout <= 64) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);

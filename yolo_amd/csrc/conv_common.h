@@ -172,10 +172,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // The streaming 1x1 kernel of conv_pw.hip (bf16 -> bf16, 128 or 256 input channels, many pixels; bit-identical to the
 // tiled kernel): whether it takes the launch, and the launch itself.
 bool conv_pw_takes(const ConvArgs& a);
 int launch_conv_pw(const ConvArgs& a, hipStream_t stream);
+
+// The patch-in-LDS 3x3 kernel of conv_patch.hip (bf16 -> bf16, stride 1, pad 1, 64 or 128 input channels, at least 96
+// output channels; bit-identical to the tiled kernel): whether it takes the launch, and the launch itself.
+bool conv_patch_takes(const ConvArgs& a);
+int launch_conv_patch(const ConvArgs& a, hipStream_t stream);
 
 }  // namespace conv
 }  // namespace ydet

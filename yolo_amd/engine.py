@@ -1018,12 +1018,37 @@ def _wide_tile_pays(M, cout, K):
     return r256 * (0.85 if K >= 256 else 1.0) < r128 - 0.02
 
 
-def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=True, stride=1, res=False):
+def _patch_kernel_takes(N, H, W, cin, cout):
+    """conv_patch_takes() / plan_patch() of csrc/conv_patch.hip for a plain 3x3 / stride 1 / pad 1 bf16 layer: whether a
+    tile of whole rows fits the LDS of a CU and the launch has a tile per CU."""
+    if cin not in (64, 128) or cout < 96 or W > 224 or os.environ.get("YDET_PATCH", "1")[:1] == "0":
+        return False
+    best = None
+    for fmw in (7, 5):
+        th = min(32 * fmw // W, H)
+        while th >= 1:
+            npad = ((th + 2) * (W + 2) + 15) // 16 * 16
+            lds = 3 * 128 * 128 + 2 * 3 * 128 * 4 + cin // 8 * npad * 16
+            if lds <= 160 * 1024 and (npad + 63) // 64 * (cin // 64) <= 12:
+                tiles = N * ((H + th - 1) // th) * ((cout + 127) // 128)
+                cost = (tiles + 255) // 256 * fmw
+                if best is None or cost < best[0]:
+                    best = (cost, tiles)
+                break
+            th -= 1
+    return best is not None and best[1] >= 256
+
+
+def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=True, stride=1, res=False, geom=None):
     """Name of the kernel instantiation ydet_conv2d_nhwc launches for this shape (mirrors launch_dtype() / launch_tile()
-    in csrc/conv.hip and conv_pw_takes() in csrc/conv_pw.hip), so that timings keyed by it line up with a profiler's
-    per-symbol statistics."""
+    in csrc/conv.hip, conv_pw_takes() in csrc/conv_pw.hip and conv_patch_takes() in csrc/conv_patch.hip), so that timings
+    keyed by it line up with a profiler's per-symbol statistics.  geom = (N, H, W) of the input map of a layer with no
+    fused upsampling, second output or 1x1 stage (the patch kernel takes whole rows of a map)."""
     if not plain:
         return "conv_direct"
+    if (geom is not None and kh == 3 and kw == 3 and pad == 1 and stride == 1 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16
+            and _patch_kernel_takes(geom[0], geom[1], geom[2], cin_phys, cout)):
+        return f"conv_patch<c{cin_phys}>"
     if (kh == 1 and kw == 1 and pad == 0 and stride == 1 and not res and in_dt == _ffi.BF16 and out_dt == _ffi.BF16
             and cin_phys in (128, 256) and cout > 64 and M >= 65536 and os.environ.get("YDET_PW", "1")[:1] != "0"):
         return f"conv_pw<k{cin_phys}>"
@@ -1075,8 +1100,10 @@ def _op_info(kind, a):
             nbytes += y.N * y.H * y.W * y.C * esz(x)
         if a.get("up") is not None:     # the first C_up channels come from a map of a quarter of the pixels
             nbytes -= x.N * x.H * x.W * a["up"][1] * esz(x) * 3 // 4
+        whole = a.get("up") is None and a.get("y2") is None and x.C == pc.cin_real and pc.groups == 1 and pc.dilation == 1
         return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W,
-                                                         plain=pc.plain, stride=a["stride"], res=a["res"] is not None),
+                                                         plain=pc.plain, stride=a["stride"], res=a["res"] is not None,
+                                                         geom=(x.N, x.H, x.W) if whole else None),
                     flops=flops,
                     bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
