@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Per-kernel means of the counters tools/pmc_conv.sh collected: python tools/pmc_conv.py gpurun_out/pmcconv_<tag>"""
+"""Per-kernel means of the counters tools/pmc_conv.sh / tools/pmc_cmd.sh collected:
+    python tools/pmc_conv.py gpurun_out/pmcconv_<tag> [kernel-name substring, default "conv"]"""
 import collections
 import csv
 import glob
 import os
 import sys
 
+FILT = sys.argv[2] if len(sys.argv) > 2 else "conv"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(os.path.join(sys.argv[1], "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
-        if "conv" in r["Kernel_Name"]:
+        if FILT in r["Kernel_Name"]:
             agg[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     print(k)

@@ -1123,6 +1123,7 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
             // 256x256p: the software-pipelined form (eight waves of 128 x 64, 128-byte rows, two stages, Cin a multiple of 64)
             if (got == 2 && strchr(forced, 'p') && a.KH * a.KW <= 32 && pipe_ok(a)) {
                 if (bn == 256 && bm == 256 && a.Cin % 64 == 0 && a.Cout > 128) return launch_tile<TIN, TOUT, 256, 256, 2, 4, 8, 2, true>(a, stream);
+                if (bn == 256 && bm == 192 && a.Cin % 64 == 0 && a.Cout > 128) return launch_tile<TIN, TOUT, 256, 192, 2, 4, 8, 2, true>(a, stream);
             }
             // <channels>x<pixels>k8s<stages>: the 128-byte-row variants (where Cin is a multiple of 64; other layers
             // keep the default choice)
@@ -1166,7 +1167,17 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
             // Cin a multiple of 64; operands within 4 GB): bit-identical, 6-15 % faster on MI355X (3x3 256 -> 512 at 38 x 38
             // 215 -> 191 us = 1.14 PFLOP/s, 3x3 512 -> 1024 at 19 x 19 238 -> 207 us, 3x3 128 -> 256 at 76 x 76 272 -> 256 us)
             static const bool pipe_on = !(getenv("YDET_CONV_PIPE") && atoi(getenv("YDET_CONV_PIPE")) == 0);
-            if (pipe_on && a.Cin % 64 == 0 && pipe_ok(a)) return launch_tile<TIN, TOUT, 256, 256, 2, 4, 8, 2, true>(a, stream);
+            if (pipe_on && a.Cin % 64 == 0 && pipe_ok(a)) {
+                // One workgroup per CU: a launch costs its rounds of 256 tiles x the tile's pixels.  Where 192-pixel tiles
+                // fill the last round and 256-pixel tiles leave it mostly empty, the narrower tile wins although it moves more
+                // bytes per FLOP (measured, bit-identical: 1x1 512 -> 256 at 38 x 38, 361 tiles vs 482: 41.0 -> 37.0 us; 3x3
+                // 512 -> 1024 at 19 x 19, 364 vs 484: 213 -> 175 us = 1.25 PFLOP/s; 1x1 1024 -> 512 at 19 x 19 38.0 -> 28.9 us;
+                // at equal cost -- 3x3 256 -> 512 at 38 x 38 -- the wide tile is 4 % faster).
+                const long long tn = (a.Cout + 255) / 256;
+                const long long r256 = ((a.M + 255) / 256 * tn + 255) / 256 * 256, r192 = ((a.M + 191) / 192 * tn + 255) / 256 * 192;
+                if (r192 * 100 < r256 * 92) return launch_tile<TIN, TOUT, 256, 192, 2, 4, 8, 2, true>(a, stream);
+                return launch_tile<TIN, TOUT, 256, 256, 2, 4, 8, 2, true>(a, stream);
+            }
             return launch_tile<TIN, TOUT, 256, 256, 4, 4>(a, stream);
         }
         // Few tiles and a long K: the launch is one or two rounds of workgroups whose time is the K loop's, and the

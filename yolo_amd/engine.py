@@ -1039,11 +1039,12 @@ def _patch_kernel_takes(N, H, W, cin, cout):
     return best is not None and best[1] >= 256
 
 
-def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=True, stride=1, res=False, geom=None):
+def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=True, stride=1, res=False, geom=None, pipe=True):
     """Name of the kernel instantiation ydet_conv2d_nhwc launches for this shape (mirrors launch_dtype() / launch_tile()
     in csrc/conv.hip, conv_pw_takes() in csrc/conv_pw.hip and conv_patch_takes() in csrc/conv_patch.hip), so that timings
     keyed by it line up with a profiler's per-symbol statistics.  geom = (N, H, W) of the input map of a layer with no
-    fused upsampling, second output or 1x1 stage (the patch kernel takes whole rows of a map)."""
+    fused upsampling, second output or 1x1 stage (the patch kernel takes whole rows of a map); pipe: the layer has no fused
+    upsampling or 1x1 stage (the software-pipelined tiles have no path for them)."""
     if not plain:
         return "conv_direct"
     if (geom is not None and kh == 3 and kw == 3 and pad == 1 and stride == 1 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16
@@ -1065,6 +1066,12 @@ def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=Tru
     if (bn == 128 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16 and cout >= 256 and (rem256 == 0 or rem256 > 128)
             and cin_phys % 32 == 0 and kh * kw <= 32 and K >= 512 and (M + 255) // 256 * ((cout + 255) // 256) >= 192
             and os.environ.get("YDET_CONV_256", "1") != "0"):
+        # (the pipelined form picks 192-pixel tiles where they fill the last round of 256 workgroups markedly better)
+        tn = (cout + 255) // 256
+        r256 = ((M + 255) // 256 * tn + 255) // 256 * 256
+        r192 = ((M + 191) // 192 * tn + 255) // 256 * 192
+        if pipe and cin_phys % 64 == 0 and os.environ.get("YDET_CONV_PIPE", "1") != "0" and r192 * 100 < r256 * 92:
+            return f"conv_dma<256x192,{dts}>"
         return f"conv_dma<256x256,{dts}>"
     if bn == 128 and dma and out_dt == _ffi.BF16 and not k8 and _wide_tile_pays(M, cout, K):
         bm = 256
@@ -1103,7 +1110,7 @@ def _op_info(kind, a):
         whole = a.get("up") is None and a.get("y2") is None and x.C == pc.cin_real and pc.groups == 1 and pc.dilation == 1
         return dict(kind="conv", label=conv_kernel_label(x.C, pc.Cout, pc.KH, pc.KW, a["pad"], x.dtype, y.dtype, M=y.N * y.H * y.W,
                                                          plain=pc.plain, stride=a["stride"], res=a["res"] is not None,
-                                                         geom=(x.N, x.H, x.W) if whole else None),
+                                                         geom=(x.N, x.H, x.W) if whole else None, pipe=a.get("up") is None),
                     flops=flops,
                     bytes=nbytes,
                     shape=(x.N, x.H, x.W, x.C, pc.Cout, pc.KH, a["stride"]))
