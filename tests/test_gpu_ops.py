@@ -1000,6 +1000,66 @@ def test_bottleneck_c32_fused(shape, add, act):
     assert (a != b).float().mean() < 0.02
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 16, 64), (1, 32, 13, 37), (2, 64, 24, 40), (1, 64, 5, 3)])
+def test_csp_resblock_fused(shape):
+    """act(x + conv3x3_noact(conv1x1(x))) -- the residual block of the CSP stages (utils/moduleUtils.py:79-91), shortcut
+    before the activation -- as the fused kernel, against torch fp32 and against the two stages run as separate convolutions
+    (same bf16 intermediate and accumulation order: one bf16 ulp, a few percent of the values)."""
+    from yolo_amd.utils.moduleUtils import CSPResBlock
+    from yolo_amd.synthetic import init_deterministic
+    m = CSPResBlock(shape[1])
+    init_deterministic(m, seed=6)
+    m.eval()
+    x = torch.randn(*shape, generator=_gen(10, f"cspres{shape}")).bfloat16().float()
+    with torch.no_grad():
+        ref = m(x.clone())
+    m = m.to(DEV)
+
+    def fused(gr, ins):
+        y = m.lower(gr, ins[0])
+        assert [k for k, _ in gr.ops][-1] == "bottleneck"
+        gr.to_nchw(y, "y")
+
+    def split(gr, ins):
+        c1, c2 = m.conv1.conv, m.conv2.conv
+        t = gr.conv(ins[0], c1[0], c1[1], act=_ffi.ACT_LEAKY, slope=0.1)
+        y = gr.conv(t, c2[0], c2[1], act=_ffi.ACT_LEAKY, slope=0.1, res=ins[0], res_mode=_ffi.RES_BEFORE_ACT)
+        gr.to_nchw(y, "y")
+
+    a = _run_graph(fused, x, compute="bf16")["y"].float().cpu()
+    b = _run_graph(split, x, compute="bf16")["y"].float().cpu()
+    assert a.shape == ref.shape
+    assert rel_err(a, ref) < 2e-2
+    assert rel_err(a, b) < 2.0 ** -8
+    assert (a != b).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("c,n", [(64, 1), (128, 2), (256, 2)])
+def test_csp_stage_lowering(c, n):
+    """CSPStage (utils/moduleUtils.py:95-107): the 32- and 64-channel stages lower to a sibling convolution with two
+    destinations, one fused kernel per residual block and conv3 over the joined halves; wider stages update the concat
+    buffer in place.  Against torch fp32."""
+    from yolo_amd.utils.moduleUtils import CSPStage
+    from yolo_amd.synthetic import init_deterministic
+    m = CSPStage(c, n=n)
+    init_deterministic(m, seed=7)
+    m.eval()
+    x = torch.randn(2, c, 21, 27, generator=_gen(12, f"cspstage{c}")).bfloat16().float()
+    with torch.no_grad():
+        ref = m(x.clone())
+    m = m.to(DEV)
+
+    def build(gr, ins):
+        y = m.lower(gr, ins[0])
+        kinds = [k for k, _ in gr.ops]
+        assert kinds.count("bottleneck") == (n if c <= 128 else 0)
+        gr.to_nchw(y, "y")
+
+    out = _run_graph(build, x, compute="bf16")["y"].float().cpu()
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 2e-2
+
+
 def test_bottleneck_c32_rejects_in_place():
     lib = _ffi.lib()
     buf = torch.zeros(1, 8, 8, 32, device=DEV, dtype=torch.bfloat16)

@@ -1,4 +1,5 @@
-// A 32- or 64-channel residual bottleneck as one kernel (the 32-channel form first): y = x + act(conv3x3(act(conv1x1(x)))) (yolov5_official/modules.py:208-218
+// A 32- or 64-channel residual bottleneck as one kernel (the 32-channel form first): y = x + act(conv3x3(act(conv1x1(x)))), or
+// y = act(x + conv3x3(act(conv1x1(x)))) -- the CSP residual block of utils/moduleUtils.py:79-91 -- (yolov5_official/modules.py:208-218
 // with c1 = c2 = c_ = 32, the first C3 stage of YOLOv5s).  Run as two convolutions this pair is bound by L2 traffic
 // (the 3x3 tap walk re-reads every input pixel nine times) and by the round trip of the intermediate map through HBM;
 // here a workgroup keeps the input patch and the intermediate patch of an 8 x 32 output tile in LDS.
@@ -32,6 +33,7 @@ struct BneckArgs {
     int act;
     float slope;
     int add;
+    int res_before;       // the shortcut goes in before the second activation: act(x + conv3x3(...)) (utils/moduleUtils.py CSPResBlock)
     int tiles_x, tiles_per_img, n_tiles;
     // C3 tail (32-channel kernel only): cv3 = 1x1 over [this bottleneck's output | z], 64 -> 64, written to y3
     const char* w3;
@@ -173,13 +175,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             // (the shortcut is a select, not a branch: the spot in xs is readable either way)
             const bf16x8 res = *reinterpret_cast<const bf16x8*>(xs + ((row + 1) * PW + col0 + 1 + px) * PITCH + q * 16);
-            const bool add = a.add != 0;
+            const bool before = a.res_before != 0, after = a.add != 0 && !before;
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v0 = act_fn<SILU>(acc0[e] + b2v[0][e], slope), v1 = act_fn<SILU>(acc1[e] + b2v[1][e], slope);
-                v0 = add ? v0 + (float)res[e] : v0;
-                v1 = add ? v1 + (float)res[4 + e] : v1;
+                const float r0 = (float)res[e], r1 = (float)res[4 + e];
+                float u0 = acc0[e] + b2v[0][e], u1 = acc1[e] + b2v[1][e];
+                u0 = before ? u0 + r0 : u0;
+                u1 = before ? u1 + r1 : u1;
+                float v0 = act_fn<SILU>(u0, slope), v1 = act_fn<SILU>(u1, slope);
+                v0 = after ? v0 + r0 : v0;
+                v1 = after ? v1 + r1 : v1;
                 o[e] = (__bf16)v0;
                 o[4 + e] = (__bf16)v1;
             }
@@ -347,12 +353,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int row = gs + u;
                 char* spot = xs + ((row + 1) * PW + 1 + px) * PITCH + co_d * 2;
                 const bf16x4 res = *reinterpret_cast<const bf16x4*>(spot);
-                const bool add = a.add != 0;
+                const bool before = a.res_before != 0, after = a.add != 0 && !before;
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = act_fn<SILU>(acc[u][e] + b2v[e], slope);
-                    v = add ? v + (float)res[e] : v;
+                    const float r = (float)res[e];
+                    float v = acc[u][e] + b2v[e];
+                    v = act_fn<SILU>(before ? v + r : v, slope);
+                    v = after ? v + r : v;
                     o[e] = (__bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(spot) = o;
@@ -416,7 +424,8 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, c
     const bool add = c2->res != nullptr;
     if (add)
         YDET_CHECK_ARG(c2->res == c1->x && c2->res_ld == c1->x_ld && c2->res_coff == c1->x_coff &&
-                           c2->res_mode == YDET_RES_AFTER_ACT, "bottleneck_fused: the residual is the block's own input, added last");
+                           (c2->res_mode == YDET_RES_AFTER_ACT || (c2->res_mode == YDET_RES_BEFORE_ACT && !c3)),
+                       "bottleneck_fused: the residual is the block's own input, added last (or, without a cv3 tail, before the second activation)");
     // the halo of a tile is read while other workgroups write their outputs: in-place operation would race
     const bool same_buf = !c3 && c2->y == c1->x && c2->y_ld == c1->x_ld;
     YDET_CHECK_ARG(!same_buf || c2->y_coff + C <= c1->x_coff || c1->x_coff + C <= c2->y_coff,
@@ -428,6 +437,7 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, c
     a.x_ld = c1->x_ld; a.x_coff = c1->x_coff; a.y_ld = c2->y_ld; a.y_coff = c2->y_coff;
     a.kp1 = c1->kp; a.kp2 = c2->kp;
     a.act = c1->act; a.slope = c1->slope; a.add = add ? 1 : 0;
+    a.res_before = add && c2->res_mode == YDET_RES_BEFORE_ACT ? 1 : 0;
     a.w3 = nullptr; a.b3 = nullptr; a.z = nullptr; a.y3 = nullptr; a.z_ld = a.z_coff = a.y3_ld = a.y3_coff = a.kp3 = 0;
     if (c3) {
         a.w3 = (const char*)c3->w; a.b3 = c3->bias; a.z = (const char*)c3->x; a.y3 = (char*)c3->y;

@@ -1136,6 +1136,7 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
         if (got == 2) {
             if (bn == 32 && bm == 256) return launch_tile<TIN, TOUT, 32, 256, 1, 4>(a, stream);
             if (bn == 64 && bm == 128) return launch_tile<TIN, TOUT, 64, 128, 1, 4>(a, stream);
+            if (bn == 64 && bm == 256) return launch_tile<TIN, TOUT, 64, 256, 1, 4>(a, stream);
             if (bn == 128 && bm == 128) return launch_tile<TIN, TOUT, 128, 128, 2, 2>(a, stream);
             if (bn == 128 && bm == 64) return launch_tile<TIN, TOUT, 128, 64, 2, 2>(a, stream);
             if (bn == 128 && bm == 256) return launch_tile<TIN, TOUT, 128, 256, 2, 4>(a, stream);

@@ -261,9 +261,10 @@ class Graph:
             self._tag_up(self.ops[-1][1])
         return out
 
-    def bottleneck(self, x, cv1, cv2, act=_ffi.ACT_NONE, slope=0.0, add=True, out=None):
+    def bottleneck(self, x, cv1, cv2, act=_ffi.ACT_NONE, slope=0.0, add=True, out=None, res_mode=_ffi.RES_AFTER_ACT):
         """x + cv2(cv1(x)) (or cv2(cv1(x)) without `add`) for cv1 = (1x1 conv, bn), cv2 = (3x3 conv, bn) sharing one
-        activation.  One fused kernel when every channel count is 32 (or 64) on the bf16 path and `out` does not alias `x`
+        activation; with res_mode = RES_BEFORE_ACT the shortcut goes in before cv2's activation: act(x + bn2(conv2(cv1(x)))).
+        One fused kernel when every channel count is 32 (or 64) on the bf16 path and `out` does not alias `x`
         (the intermediate map then never exists in HBM); otherwise two convolutions."""
         (c1, bn1), (c2, bn2) = cv1, cv2
         geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups if is_plain(c) else -1)
@@ -274,7 +275,7 @@ class Graph:
                       or x.resolve()[1] + Cc <= out.resolve()[1]))
         if not fused:
             t = self.conv(x, c1, bn1, act=act, slope=slope)
-            return self.conv(t, c2, bn2, act=act, slope=slope, res=x if add else None, res_mode=_ffi.RES_AFTER_ACT, out=out)
+            return self.conv(t, c2, bn2, act=act, slope=slope, res=x if add else None, res_mode=res_mode, out=out)
         pc1 = pack_conv(c1, bn1, None, cin_phys=Cc, dtype=self.dt, device=self.device)
         pc2 = pack_conv(c2, bn2, None, cin_phys=Cc, dtype=self.dt, device=self.device)
         self.keep += [pc1, pc2]
@@ -286,7 +287,7 @@ class Graph:
             x=x, y=out, add=bool(add), pc=pc1, pc2=pc2,
             cv1=dict(common, res=None, pc=pc1, stride=1, pad=0, res_mode=_ffi.RES_NONE),
             cv2=dict(common, res=x if add else None, pc=pc2, stride=1, pad=1,
-                     res_mode=_ffi.RES_AFTER_ACT if add else _ffi.RES_NONE))))
+                     res_mode=res_mode if add else _ffi.RES_NONE))))
         return out
 
     def c3_tail(self, x, cv1, cv2, other, cv3, act=_ffi.ACT_NONE, slope=0.0, add=True):

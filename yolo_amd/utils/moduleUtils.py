@@ -96,7 +96,11 @@ class CSPResBlock(nn.Module):
 
     def lower(self, g, x, out=None):
         act, slope = activation_code(self.act)
-        c2 = self.conv2.conv
+        c1, c2 = self.conv1.conv, self.conv2.conv
+        if activation_code(c1[2]) == (act, slope) and c2[0].out_channels == x.C:
+            # (one kernel for the 32- and 64-channel blocks when `out` is not `x`, two convolutions otherwise)
+            return g.bottleneck(x, (c1[0], c1[1]), (c2[0], c2[1]), act=act, slope=slope, add=True, out=out,
+                                res_mode=_ffi.RES_BEFORE_ACT)
         return g.conv(self.conv1.lower(g, x), c2[0], c2[1], act=act, slope=slope, res=x,
                       res_mode=_ffi.RES_BEFORE_ACT, out=out)
 
@@ -117,7 +121,18 @@ class CSPStage(nn.Module):
 
     def lower(self, g, x):
         h = self.conv1.conv[0].out_channels
-        if h % g.vec == 0 and all(b.conv2.conv[0].out_channels == h for b in self.resblock):
+        act, slope = activation_code(self.conv1.conv[2])
+        same = all(b.conv2.conv[0].out_channels == h for b in self.resblock)
+        if same and h in (32, 64) and g.dt == _ffi.BF16 and x.C % 32 == 0:
+            # 32- and 64-channel residual blocks run as one kernel each, which must not work in place (it reads a halo):
+            # the sibling convolution sends its halves to buffers of their own, every block writes a new map, and the concat
+            # in front of conv3 joins conv1's half with the last block's output
+            _, (y1, y2) = g.conv_siblings(x, [(self.conv1.conv[0], self.conv1.conv[1]),
+                                              (self.conv2.conv[0], self.conv2.conv[1])], act, slope, separate=True)
+            for blk in self.resblock:
+                y2 = blk.lower(g, y2)
+            return self.conv3.lower(g, g.cat([y1, y2]))
+        if h % g.vec == 0 and same:
             # conv1 and conv2 read the same input: one convolution writes [conv1(x) | conv2(x)] into the concat
             # buffer and the residual blocks update the second half in place
             act, slope = activation_code(self.conv1.conv[2])
