@@ -607,7 +607,7 @@ def other_configs(dev, args, rank, world):
         # Batches are issued round-robin on HIP streams like the headline's (each stream has its own plan and activation
         # arena): the per-class NMS of one batch (vector ALU work on a few workgroups) runs under the next batch's
         # convolutions.  A single image (C1) is a latency measurement: one stream.
-        S = 1 if batch == 1 else max(1, min(args.streams, 2))
+        S = 1 if batch == 1 else max(1, args.streams)
         streams = [torch.cuda.Stream(dev) for _ in range(S)]
         with torch.no_grad():
             for k in range(2 * S):

@@ -1034,6 +1034,48 @@ def test_csp_resblock_fused(shape):
     assert (a != b).float().mean() < 0.02
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32), (1, 64, 13, 37), (3, 64, 40, 24), (1, 64, 5, 3)])
+@pytest.mark.parametrize("act", ["leaky", "silu"])
+def test_resblock_c64_fused(shape, act):
+    """x + Conv3x3(Conv1x1(x)) with a 1x1 that halves the 64 channels (utils/moduleUtils.py:45-59, the first residual stage
+    of Darknet-53) as one kernel, tile-aligned and ragged maps: against torch fp32 and against the two stages run as
+    separate convolutions (same bf16 intermediate and accumulation order: one bf16 ulp, a few percent of the values)."""
+    from yolo_amd.utils.moduleUtils import resblock
+    from yolo_amd.synthetic import init_deterministic
+    m = resblock(shape[1], nblocks=2)
+    if act == "silu":
+        for pair in m.module_list:
+            pair[0].conv[2] = nn.SiLU()
+            pair[1].conv[2] = nn.SiLU()
+    init_deterministic(m, seed=8)
+    m.eval()
+    x = torch.randn(*shape, generator=_gen(13, f"resblock{shape}")).bfloat16().float()
+    with torch.no_grad():
+        ref = m(x.clone())
+    m = m.to(DEV)
+    code, slope = (_ffi.ACT_SILU, 0.0) if act == "silu" else (_ffi.ACT_LEAKY, 0.1)
+
+    def fused(gr, ins):
+        y = m.lower(gr, ins[0])
+        assert [k for k, _ in gr.ops][-2:] == ["bottleneck", "bottleneck"]
+        gr.to_nchw(y, "y")
+
+    def split(gr, ins):
+        y = ins[0]
+        for pair in m.module_list:
+            c1, c2 = pair[0].conv, pair[1].conv
+            t = gr.conv(y, c1[0], c1[1], act=code, slope=slope)
+            y = gr.conv(t, c2[0], c2[1], act=code, slope=slope, res=y, res_mode=_ffi.RES_AFTER_ACT)
+        gr.to_nchw(y, "y")
+
+    a = _run_graph(fused, x, compute="bf16")["y"].float().cpu()
+    b = _run_graph(split, x, compute="bf16")["y"].float().cpu()
+    assert a.shape == ref.shape
+    assert rel_err(a, ref) < 2e-2
+    assert rel_err(a, b) < 2.0 ** -7
+    assert (a != b).float().mean() < 0.04
+
+
 @pytest.mark.parametrize("c,n", [(64, 1), (128, 2), (256, 2)])
 def test_csp_stage_lowering(c, n):
     """CSPStage (utils/moduleUtils.py:95-107): the 32- and 64-channel stages lower to a sibling convolution with two

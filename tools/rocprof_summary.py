@@ -49,7 +49,7 @@ def label_of(name):
         return f"conv_generic<{bn}x{bm},{'1x1' if one else 'kxk'},{dts}>"
     if "bottleneck_c32" in name and ("kernel<true" in name or "ILb1E" in name):
         return "conv_c3_tail_c32"
-    for key, lab in (("focus_pair", "conv_focus_pair"), ("focus_conv3x3", "conv_focus3x3"), ("bottleneck_c32", "conv_bottleneck_c32"), ("bottleneck_c64", "conv_bottleneck_c64"), ("decode_v5", "decode_v5"), ("v5_pick", "nms_v5_pick"),
+    for key, lab in (("focus_pair", "conv_focus_pair"), ("focus_conv3x3", "conv_focus3x3"), ("bottleneck_c32", "conv_bottleneck_c32"), ("bottleneck_c64", "conv_bottleneck_c64"), ("resblock_c64", "conv_resblock_c64"), ("decode_v5", "decode_v5"), ("v5_pick", "nms_v5_pick"),
                      ("v5_nms", "nms_v5_greedy"), ("v5_rank", "nms_v5_rank"), ("v5_rowmax", "nms_v5_rowmax"),
                      ("v5_exact", "nms_v5_exact_select"), ("spp_lds", "spp"), ("upsample2x", "upsample"),
                      ("nchw_to_nhwc", "nchw2nhwc")):

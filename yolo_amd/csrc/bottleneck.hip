@@ -379,6 +379,153 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- 64 -> 32 -> 64 channels: the residual block of the Darknet-53 trunk at half the image size ---------------------------
+// x + act(conv3x3(act(conv1x1(x)))) with a 1x1 that halves the channels (utils/moduleUtils.py:45-59, resblock(64)): run as
+// two convolutions the pair writes and re-reads the 32-channel map -- 378 MB for 64 images of 608 x 608 -- and the 3x3, with
+// K = 288 and 64 output channels, leaves the matrix pipe mostly idle.  Same scheme as above on an 8 x 16 output tile:
+// xs = input patch (64 channels, 160-byte pitch), ts = act(conv1x1) of the patch (32 channels, 96-byte pitch, zero outside
+// the image).  1x1 stage: every wave takes all 32 channels (two A fragments x two K steps) of a quarter of the pixel
+// groups.  3x3 stage: the waves split 2 (channel halves) x 2 (row halves), 18 A fragments each in registers, a pixel
+// fragment feeds two MFMAs.
+#ifndef RB64_WPE
+#define RB64_WPE 2
+#endif
+namespace rb64 {
+constexpr int TH = 8, TW = 16;
+constexpr int PH = TH + 2, PW = TW + 2;
+constexpr int NPIX = PH * PW;                   // 180 patch pixels
+constexpr int NGRP = (NPIX + 15) / 16;          // 12 groups (the last one reads 12 pixels past xs, into ts: dropped)
+constexpr int XP = 160, TP = 96;
+constexpr int XS_BYTES = NPIX * XP, TS_BYTES = NPIX * TP;
+constexpr int NLOAD = (NPIX * 8 + 255) / 256;
+static_assert(NGRP * 16 * XP <= XS_BYTES + TS_BYTES, "the last pixel group of the 1x1 stage stays inside the array");
+static_assert(NGRP % 4 == 0, "pixel groups split evenly over four waves");
+}  // namespace rb64
+
+template <bool SILU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB64_WPE, RB64_WPE))) void resblock_c64_kernel(const BneckArgs a) {
+    constexpr int TH = rb64::TH, TW = rb64::TW, PW = rb64::PW, NPIX = rb64::NPIX, NGRP = rb64::NGRP, XP = rb64::XP, TP = rb64::TP;
+    constexpr int NLOAD = rb64::NLOAD;
+    __shared__ __attribute__((aligned(16))) char smem[rb64::XS_BYTES + rb64::TS_BYTES];
+    char* xs = smem;
+    char* ts = smem + rb64::XS_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, q = lane >> 4;
+    const int hc = wave & 1, hr = wave >> 1;      // 3x3 stage: channel half, row half
+    const float slope = a.act == YDET_ACT_LEAKY ? a.slope : 1.0f;   // ACT_NONE: leaky with slope 1
+
+    // A row r of fragment i is channel (r>>2)*8 + i*4 + (r&3) of its 32: the D rows a lane holds (4q..4q+3 of both
+    // fragments) are then eight consecutive channels, one 16-byte piece.
+    const int arow = lane & 15;
+    bf16x8 w1f[2][2], w2f[9][2];
+    float b1v[2][4], b2v[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co = (arow >> 2) * 8 + i * 4 + (arow & 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            w1f[i][s] = *reinterpret_cast<const bf16x8*>(a.w1 + ((size_t)co * a.kp1 + s * 32 + q * 8) * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            w2f[t][i] = *reinterpret_cast<const bf16x8*>(a.w2 + ((size_t)(32 * hc + co) * a.kp2 + t * 32 + q * 8) * 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b1v[i][e] = a.b1[q * 8 + i * 4 + e];
+            b2v[i][e] = a.b2[32 * hc + q * 8 + i * 4 + e];
+        }
+    }
+
+    uint4 pre[NLOAD];
+    auto fetch = [&](int tile) {
+        const int n = tile / a.tiles_per_img, r = tile - n * a.tiles_per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * 256, p = idx >> 3, ch = idx & 7;
+            const int pr = p / PW, pc = p - pr * PW;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = p < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            pre[k] = uint4{0, 0, 0, 0};
+            if (ok)
+                pre[k] = *reinterpret_cast<const uint4*>(a.x + ((((size_t)n * a.H + iy) * a.W + ix) * a.x_ld + a.x_coff + ch * 8) * 2);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.n_tiles) fetch(tile);
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        const int n = tile / a.tiles_per_img, r = tile - n * a.tiles_per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        // ---- patch -> LDS ---------------------------------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            const int idx = tid + k * 256, p = idx >> 3, ch = idx & 7;
+            if (p < NPIX) *reinterpret_cast<uint4*>(xs + p * XP + ch * 16) = pre[k];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.n_tiles) fetch(tile + gridDim.x);   // lands while this tile is computed
+        // ---- 1x1 over the whole patch -> ts (zero where the patch leaves the image: the 3x3's padding) -----------
+#pragma unroll
+        for (int gi = 0; gi < NGRP / 4; ++gi) {
+            const int p = (wave + 4 * gi) * 16 + px;
+            const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xs + p * XP + q * 16);
+            const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xs + p * XP + 64 + q * 16);
+            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[0][0], x0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[1][0], x0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[0][1], x1, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[1][1], x1, acc1, 0, 0, 0);
+            const int pr = p / PW, pc = p - pr * PW;
+            const bool in = p < NPIX && (unsigned)(oy0 - 1 + pr) < (unsigned)a.H && (unsigned)(ox0 - 1 + pc) < (unsigned)a.W;
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = act_fn<SILU>(acc0[e] + b1v[0][e], slope), v1 = act_fn<SILU>(acc1[e] + b1v[1][e], slope);
+                t[e] = (__bf16)(in ? v0 : 0.f);
+                t[4 + e] = (__bf16)(in ? v1 : 0.f);
+            }
+            if (p < NPIX) *reinterpret_cast<bf16x8*>(ts + p * TP + q * 16) = t;
+        }
+        __syncthreads();
+        // ---- 3x3 over ts, + residual, -> y: this wave's 32 channels of its four output rows ------------------------
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int row = 4 * hr + gi;
+            const int oy = oy0 + row, ox = ox0 + px;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int p = (row + t / 3) * PW + t % 3 + px;
+                const bf16x8 tb = *reinterpret_cast<const bf16x8*>(ts + p * TP + q * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t][0], tb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t][1], tb, acc1, 0, 0, 0);
+            }
+            // (the shortcut is a select, not a branch: the spot in xs is readable either way)
+            const bf16x8 res = *reinterpret_cast<const bf16x8*>(xs + ((row + 1) * PW + 1 + px) * XP + hc * 64 + q * 16);
+            const bool before = a.res_before != 0, after = a.add != 0 && !before;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r0 = (float)res[e], r1 = (float)res[4 + e];
+                float u0 = acc0[e] + b2v[0][e], u1 = acc1[e] + b2v[1][e];
+                u0 = before ? u0 + r0 : u0;
+                u1 = before ? u1 + r1 : u1;
+                float v0 = act_fn<SILU>(u0, slope), v1 = act_fn<SILU>(u1, slope);
+                v0 = after ? v0 + r0 : v0;
+                v1 = after ? v1 + r1 : v1;
+                o[e] = (__bf16)v0;
+                o[4 + e] = (__bf16)v1;
+            }
+            if (oy < a.H && ox < a.W)
+                *reinterpret_cast<bf16x8*>(a.y + ((((size_t)n * a.H + oy) * a.W + ox) * a.y_ld + a.y_coff + 32 * hc + q * 8) * 2) = o;
+        }
+        __syncthreads();   // xs / ts are rewritten by the next tile
+    }
+}
+
 }  // namespace
 
 int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, const ydet_conv_desc* c3, hipStream_t stream) {
@@ -389,14 +536,15 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, c
     YDET_CHECK_ARG(c1->x && c1->w && c1->bias && c2->w && c2->bias && (c2->y || c3), "bottleneck_fused: null x/w/bias/y pointer");
     YDET_CHECK_ARG(c1->in_dtype == YDET_BF16 && c1->out_dtype == YDET_BF16 && c2->in_dtype == YDET_BF16 &&
                        c2->out_dtype == YDET_BF16, "bottleneck_fused: bf16 only");
-    const int C = c1->Cin;
-    YDET_CHECK_ARG((C == 32 || C == 64) && c1->Cout == C && c2->Cin == C && c2->Cout == C,
-                   "bottleneck_fused: 32 or 64 channels throughout");
+    const int C = c1->Cin, Cm = c1->Cout;         // block channels, channels between the two stages
+    YDET_CHECK_ARG(((C == 32 || C == 64) && Cm == C && c2->Cin == C && c2->Cout == C) ||
+                       (C == 64 && Cm == 32 && c2->Cin == 32 && c2->Cout == 64 && !c3),
+                   "bottleneck_fused: 32 or 64 channels throughout, or 64 -> 32 -> 64");
     YDET_CHECK_ARG(c1->KH == 1 && c1->KW == 1 && c1->stride == 1 && c1->pad == 0 && c2->KH == 3 && c2->KW == 3 &&
                        c2->stride == 1 && c2->pad == 1, "bottleneck_fused: a 1x1 followed by a 3x3 / stride 1 / pad 1");
     YDET_CHECK_ARG(c1->N > 0 && c1->H > 0 && c1->W > 0 && c2->N == c1->N && c2->H == c1->H && c2->W == c1->W &&
                        c2->Ho == c1->H && c2->Wo == c1->W, "bottleneck_fused: shapes of the two stages differ");
-    YDET_CHECK_ARG(c1->kp == C && c2->kp == 9 * C && c1->cout_pad >= C && c2->cout_pad >= C, "bottleneck_fused: kp %d / %d",
+    YDET_CHECK_ARG(c1->kp == C && c2->kp == 9 * Cm && c1->cout_pad >= Cm && c2->cout_pad >= C, "bottleneck_fused: kp %d / %d",
                    c1->kp, c2->kp);
     YDET_CHECK_ARG(c1->act == c2->act && c1->slope == c2->slope && c1->act >= 0 && c1->act <= 2,
                    "bottleneck_fused: both stages share one activation");
@@ -464,6 +612,10 @@ int ydet_launch_bottleneck(const ydet_conv_desc* c1, const ydet_conv_desc* c2, c
     } else if (C == 32) {
         if (silu) hipLaunchKernelGGL((bottleneck_c32_kernel<false, true>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((bottleneck_c32_kernel<false, false>), g, b, 0, stream, a);
+    } else if (Cm == 32) {
+        const dim3 g3((unsigned)(n_tiles < (long long)RB64_WPE * cus ? n_tiles : (long long)RB64_WPE * cus));
+        if (silu) hipLaunchKernelGGL(resblock_c64_kernel<true>, g3, b, 0, stream, a);
+        else hipLaunchKernelGGL(resblock_c64_kernel<false>, g3, b, 0, stream, a);
     } else {
         if (silu) hipLaunchKernelGGL(bottleneck_c64_kernel<true>, g, b, 0, stream, a);
         else hipLaunchKernelGGL(bottleneck_c64_kernel<false>, g, b, 0, stream, a);

@@ -264,12 +264,14 @@ class Graph:
     def bottleneck(self, x, cv1, cv2, act=_ffi.ACT_NONE, slope=0.0, add=True, out=None, res_mode=_ffi.RES_AFTER_ACT):
         """x + cv2(cv1(x)) (or cv2(cv1(x)) without `add`) for cv1 = (1x1 conv, bn), cv2 = (3x3 conv, bn) sharing one
         activation; with res_mode = RES_BEFORE_ACT the shortcut goes in before cv2's activation: act(x + bn2(conv2(cv1(x)))).
-        One fused kernel when every channel count is 32 (or 64) on the bf16 path and `out` does not alias `x`
-        (the intermediate map then never exists in HBM); otherwise two convolutions."""
+        One fused kernel when every channel count is 32 (or 64), or the channels go 64 -> 32 -> 64, on the bf16 path and
+        `out` does not alias `x` (the intermediate map then never exists in HBM); otherwise two convolutions."""
         (c1, bn1), (c2, bn2) = cv1, cv2
         geom = lambda c: (c.kernel_size[0], c.stride[0], c.padding[0], c.groups if is_plain(c) else -1)
         Cc = x.C
-        fused = (self.dt == _ffi.BF16 and Cc in (32, 64) and c1.out_channels == Cc and c2.out_channels == Cc
+        Cm = c1.out_channels                  # channels between the stages: Cc, or 32 under a 64-channel block
+        fused = (self.dt == _ffi.BF16 and ((Cc in (32, 64) and Cm == Cc) or (Cc == 64 and Cm == 32)) and c2.out_channels == Cc
+                 and c1.in_channels == Cc and c2.in_channels == Cm
                  and geom(c1) == (1, 1, 0, 1) and geom(c2) == (3, 1, 1, 1) and x.dtype == _ffi.BF16
                  and (out is None or out.resolve()[0] is not x.resolve()[0] or out.resolve()[1] + Cc <= x.resolve()[1]
                       or x.resolve()[1] + Cc <= out.resolve()[1]))
@@ -277,7 +279,7 @@ class Graph:
             t = self.conv(x, c1, bn1, act=act, slope=slope)
             return self.conv(t, c2, bn2, act=act, slope=slope, res=x if add else None, res_mode=res_mode, out=out)
         pc1 = pack_conv(c1, bn1, None, cin_phys=Cc, dtype=self.dt, device=self.device)
-        pc2 = pack_conv(c2, bn2, None, cin_phys=Cc, dtype=self.dt, device=self.device)
+        pc2 = pack_conv(c2, bn2, None, cin_phys=Cm, dtype=self.dt, device=self.device)
         self.keep += [pc1, pc2]
         if out is None:
             out = self.new(x.N, x.H, x.W, Cc)
@@ -715,6 +717,7 @@ class Plan:
             assert not a["x"].resolve()[0].external and not a["y"].resolve()[0].external
             self._fill_conv(op, i, a["cv1"], arena, record)
             self._fill_conv(op, i, a["cv2"], arena, record, d=op.conv2)
+            op.conv2.Cin = a["pc"].Cout           # (the record's x is the block's input: the second stage reads the first's output)
             op.kind = _ffi.OP_BOTTLENECK
         elif kind == "c3tail":
             assert not any(a[k].resolve()[0].external for k in ("x", "y", "other"))
@@ -1123,9 +1126,9 @@ def _op_info(kind, a):
     if kind == "bottleneck":
         x, y = a["x"], a["y"]
         px = y.N * y.H * y.W
-        Cc = x.C
-        return dict(kind="conv", label=f"conv_bottleneck_c{Cc}", flops=2.0 * px * Cc * Cc * 10,
-                    bytes=px * Cc * 2 * 2 + 10 * Cc * Cc * 2, shape=(x.N, x.H, x.W, Cc, Cc, 3, 1))
+        Cc, Cm = x.C, a["pc"].Cout
+        return dict(kind="conv", label=f"conv_bottleneck_c{Cc}" if Cm == Cc else f"conv_resblock_c{Cc}", flops=2.0 * px * Cc * Cm * 10,
+                    bytes=px * Cc * 2 * 2 + 10 * Cc * Cm * 2, shape=(x.N, x.H, x.W, Cc, Cc, 3, 1))
     if kind == "rgb_conv":
         y, pc = a["y"], a["pc"]
         return dict(kind="conv", label="conv_rgb3x3", flops=2.0 * a["N"] * a["H"] * a["W"] * pc.Cout * 27,

@@ -61,7 +61,13 @@ class resblock(nn.Module):
 
     def lower(self, g, x):
         for pair in self.module_list:
-            x = pair[1].lower(g, pair[0].lower(g, x), res=x)
+            c1, c2 = pair[0].conv, pair[1].conv
+            a1, a2 = activation_code(c1[2] if len(c1) > 2 else None), activation_code(c2[2] if len(c2) > 2 else None)
+            if a1 == a2:
+                # (one kernel for the 64 -> 32 -> 64 block of the first stage, two convolutions for the wider ones)
+                x = g.bottleneck(x, (c1[0], c1[1]), (c2[0], c2[1]), act=a1[0], slope=a1[1], add=True)
+            else:
+                x = pair[1].lower(g, pair[0].lower(g, x), res=x)
         return x
 
 
