@@ -40,8 +40,9 @@ GFLOP_PER_IMAGE = 16.96   # YOLOv5s nc=80 at 640x640, conv MACs x 2 (measured on
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # (a step is about 2 ms: a hundred of them keep the ramp-up and the drain of the three streams a small share of the timed region)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeat", type=int, default=0, help="diagnostic: time the K steps this many more times (reported as repeat_ms)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=640)
