@@ -568,7 +568,7 @@ def test_conv_pw_streaming_equals_tiled(geom):
 
 @pytest.mark.parametrize("geom", [(32, 40, 40, 128, 512, 3, 1, True), (31, 41, 39, 64, 400, 3, 1, False), (30, 44, 44, 512, 256, 1, 1, False),
                                   (32, 40, 40, 96, 256, 3, 1, False), (32, 80, 80, 128, 256, 3, 2, False), (25, 38, 38, 256, 512, 3, 1, True),
-                                  (64, 38, 38, 512, 256, 1, 1, True), (61, 19, 19, 192, 700, 3, 1, False)])
+                                  (64, 38, 38, 512, 256, 1, 1, True), (61, 19, 19, 192, 700, 3, 1, False), (64, 19, 19, 256, 512, 3, 1, True)])
 def test_conv_256_tile_equals_small_launch(geom):
     """Wide layers with a long K and about a tile per CU take the 256 x 256 tile -- eight waves with the software-pipelined
     K loop and buffer-addressed operands (padding taps and rows beyond the last pixel are out-of-range offsets that read
@@ -576,7 +576,7 @@ def test_conv_256_tile_equals_small_launch(geom):
     128-wide tile.  Same MFMA, same K order, same epilogue: every image equals its own single-image run bit for bit
     (ragged channel tile: 400 = 256 + 144; ragged pixel tiles; residual; stride 2; K = 2304).  The last two shapes take the
     256 x 192 form of the pipelined tile (its last round of workgroups fills better: 482 tiles instead of 361; 345 instead
-    of 261 with a ragged channel tile 700 = 512 + 188)."""
+    of 261 with a ragged channel tile 700 = 512 + 188; 242 instead of 182, which alone would be too few for a wide tile)."""
     N, H, W, cin, cout, k, s, res = geom
     gen = _gen(43, f"t256{geom}")
     p = k // 2
@@ -587,7 +587,7 @@ def test_conv_256_tile_equals_small_launch(geom):
     conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (cin * k * k)) ** 0.5)
     conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
     lab = engine.conv_kernel_label(cin, cout, k, k, p, _ffi.BF16, _ffi.BF16, M=N * Ho * Wo, stride=s, res=res)
-    assert lab.startswith("conv_dma<256x192" if geom[:3] in ((64, 38, 38), (61, 19, 19)) else "conv_dma<256x")
+    assert lab.startswith("conv_dma<256x192" if geom[:3] in ((64, 38, 38), (61, 19, 19), (64, 19, 19)) else "conv_dma<256x")
     assert not engine.conv_kernel_label(cin, cout, k, k, p, _ffi.BF16, _ffi.BF16, M=Ho * Wo, stride=s,
                                         res=res).startswith("conv_dma<256x256")
 

@@ -1161,14 +1161,17 @@ int launch_dtype(const ConvArgs& a, hipStream_t stream) {
         // most of the chip idle (37 -> 63 us).  YDET_CONV_256=0 turns the rule off.
         static const bool t256_on = !(getenv("YDET_CONV_256") && atoi(getenv("YDET_CONV_256")) == 0);
         const int rem256 = a.Cout % 256;
-        const long long tiles256 = (a.M + 255) / 256 * ((a.Cout + 255) / 256);
+        const long long tiles256 = (a.M + 255) / 256 * ((a.Cout + 255) / 256), tiles192 = (a.M + 191) / 192 * ((a.Cout + 255) / 256);
+        static const bool pipe_on = !(getenv("YDET_CONV_PIPE") && atoi(getenv("YDET_CONV_PIPE")) == 0);
+        const bool piped = pipe_on && a.Cin % 64 == 0 && pipe_ok(a);
+        // (the pipelined form also comes with 192-pixel tiles: 182 tiles of 256 pixels leave a quarter of the CUs idle where
+        // 242 of 192 pixels fill them -- YOLOv4's 19 x 19 layers with 512 output channels)
         if (t256_on && a.Cout >= 256 && (rem256 == 0 || rem256 > 128) && a.Cin % 32 == 0 && a.KH * a.KW <= 32 &&
-            a.KH * a.KW * a.Cin >= 512 && tiles256 >= 192 && a.splits <= 1) {
+            a.KH * a.KW * a.Cin >= 512 && (piped ? tiles192 : tiles256) >= 192 && a.splits <= 1) {
             // ... as eight waves of 128 x 64 with the software-pipelined K loop where the shape allows it (128-byte rows:
             // Cin a multiple of 64; operands within 4 GB): bit-identical, 6-15 % faster on MI355X (3x3 256 -> 512 at 38 x 38
             // 215 -> 191 us = 1.14 PFLOP/s, 3x3 512 -> 1024 at 19 x 19 238 -> 207 us, 3x3 128 -> 256 at 76 x 76 272 -> 256 us)
-            static const bool pipe_on = !(getenv("YDET_CONV_PIPE") && atoi(getenv("YDET_CONV_PIPE")) == 0);
-            if (pipe_on && a.Cin % 64 == 0 && pipe_ok(a)) {
+            if (piped) {
                 // One workgroup per CU: a launch costs its rounds of 256 tiles x the tile's pixels.  Where 192-pixel tiles
                 // fill the last round and 256-pixel tiles leave it mostly empty, the narrower tile wins although it moves more
                 // bytes per FLOP (measured, bit-identical: 1x1 512 -> 256 at 38 x 38, 361 tiles vs 482: 41.0 -> 37.0 us; 3x3

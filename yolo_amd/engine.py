@@ -1067,14 +1067,15 @@ def conv_kernel_label(cin_phys, cout, kh, kw, pad, in_dt, out_dt, M=0, plain=Tru
     k8 = (bn == 128 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16 and cin_phys % 64 == 0 and kh * kw <= 32 and K >= 256
           and (tiles <= 512 or (tiles <= 1024 and K >= 2048)) and os.environ.get("YDET_CONV_K8", "1") != "0")
     rem256 = cout % 256
+    tn = (cout + 255) // 256
+    piped = pipe and cin_phys % 64 == 0 and os.environ.get("YDET_CONV_PIPE", "1") != "0"
     if (bn == 128 and in_dt == _ffi.BF16 and out_dt == _ffi.BF16 and cout >= 256 and (rem256 == 0 or rem256 > 128)
-            and cin_phys % 32 == 0 and kh * kw <= 32 and K >= 512 and (M + 255) // 256 * ((cout + 255) // 256) >= 192
+            and cin_phys % 32 == 0 and kh * kw <= 32 and K >= 512 and (M + (191 if piped else 255)) // (192 if piped else 256) * tn >= 192
             and os.environ.get("YDET_CONV_256", "1") != "0"):
         # (the pipelined form picks 192-pixel tiles where they fill the last round of 256 workgroups markedly better)
-        tn = (cout + 255) // 256
         r256 = ((M + 255) // 256 * tn + 255) // 256 * 256
         r192 = ((M + 191) // 192 * tn + 255) // 256 * 192
-        if pipe and cin_phys % 64 == 0 and os.environ.get("YDET_CONV_PIPE", "1") != "0" and r192 * 100 < r256 * 92:
+        if piped and r192 * 100 < r256 * 92:
             return f"conv_dma<256x192,{dts}>"
         return f"conv_dma<256x256,{dts}>"
     if bn == 128 and dma and out_dt == _ffi.BF16 and not k8 and _wide_tile_pays(M, cout, K):
