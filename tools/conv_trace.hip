@@ -15,9 +15,17 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 void clear_error() {}
-namespace conv {   // the persistent kernel lives in another translation unit of the library; not traced here
-bool conv_big_takes(const ConvArgs&) { return false; }
-int launch_conv_big(const ConvArgs&, hipStream_t) { return YDET_ERR_ARG; }
+DeviceInfo current_device_info() { return DeviceInfo{256, 160 * 1024}; }
+int raise_dynamic_lds_limit(const void* kernel, int bytes, unsigned char (&)[kMaxDevices], const char* what) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return fail(YDET_ERR_ARG, "%s: dynamic LDS limit", what);
+    return YDET_OK;
+}
+namespace conv {   // the streaming 1x1 and patch kernels live in other translation units of the library; not traced here
+bool conv_pw_takes(const ConvArgs&) { return false; }
+int launch_conv_pw(const ConvArgs&, hipStream_t) { return YDET_ERR_ARG; }
+bool conv_patch_takes(const ConvArgs&) { return false; }
+int launch_conv_patch(const ConvArgs&, hipStream_t) { return YDET_ERR_ARG; }
 }  // namespace conv
 }  // namespace ydet
 
