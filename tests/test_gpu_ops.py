@@ -636,6 +636,35 @@ def test_conv_patch_equals_tiled_launch(geom):
         assert torch.equal(one[0], full[n]), f"image {n}"
 
 
+def test_conv_patch_on_channel_slices():
+    """The patch kernel on operands that are channel slices of wider buffers -- input = channels 64 .. 191 of a 256-channel
+    map, residual = that same slice, output = the first half of a concat buffer whose other half another layer writes:
+    every image equals its single-image run (tiled kernel), and torch fp32 within the bf16 bar."""
+    N, H, W = 56, 23, 40
+    assert engine.conv_kernel_label(128, 128, 3, 3, 1, _ffi.BF16, _ffi.BF16, M=N * H * W, res=True, geom=(N, H, W)) == "conv_patch<c128>"
+    gen = _gen(48, "patchslices")
+    x = torch.randn(N, 256, H, W, generator=gen).bfloat16().float()
+    conv = nn.Conv2d(128, 128, 3, 1, 1).requires_grad_(False)
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * (2.0 / (128 * 9)) ** 0.5)
+    conv.bias.copy_(torch.randn(128, generator=gen) * 0.1)
+    other = nn.Conv2d(256, 64, 1).requires_grad_(False)
+    other.weight.copy_(torch.randn(other.weight.shape, generator=gen) * (2.0 / 256) ** 0.5)
+    other.bias.zero_()
+
+    def build(gr, ins):
+        xin = gr.slice(ins[0], 64, 128)
+        y = gr.conv(xin, conv, act=_ffi.ACT_SILU, res=xin, res_mode=_ffi.RES_AFTER_ACT)
+        z = gr.conv(ins[0], other, act=_ffi.ACT_SILU)
+        gr.to_nchw(gr.cat([y, z]), "y")
+
+    full = _run_graph(build, x, compute="bf16")["y"].float().cpu()
+    ref = torch.cat([F.silu(conv(x[:, 64:192])) + x[:, 64:192], F.silu(other(x))], 1)
+    assert rel_err(full.numpy(), ref.numpy()) < 2e-2
+    for n in (0, N - 1):
+        one = _run_graph(build, x[n:n + 1], compute="bf16")["y"].float().cpu()
+        assert torch.equal(one[0], full[n]), f"image {n}"
+
+
 GROUPED_CASES = [
     # N, H, W, Cin, Cout, k, s, p, groups, dilation, act, residual
     (2, 20, 20, 64, 64, 3, 1, 1, 64, 1, "silu", None),       # depthwise (DWConv, yolov5_official/modules.py:19-21)
