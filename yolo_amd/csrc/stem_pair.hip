@@ -21,8 +21,10 @@
 //
 // RGB variant (the Darknet-style trunks of the v3 / v4 detectors, models/basemodel/d19.py:83-123 and :215-265, whose first
 // two layers are Conv(3, 32, 3, p=1) and Conv(32, 64, 3, p=1, s=2)): no slicing, F holds the 19 x 35 image pixels
-// themselves (3 channels + 13 zeros per slot, weights packed the same way: k = tap * 16 + channel), everything from P1
-// on is shared.  The 32-channel map at FULL image size -- 1.5 GB for 64 images of 608 x 608 -- is never written.
+// themselves in 8-byte slots (3 channels + a zero), K is tap-major with 4 channels per tap (k = tap * 4 + channel:
+// 36 -> 64, the packing of the stand-alone first-layer kernel of stem.hip), so P1 is TWO K steps per pixel group -- a
+// lane's eight k-values are two taps, two 8-byte LDS reads -- where 16-channel slots would make it five; everything
+// behind P1 is shared.  The 32-channel map at FULL image size -- 1.5 GB for 64 images of 608 x 608 -- is never written.
 #include <type_traits>
 
 #include "ydet_internal.h"
@@ -174,27 +176,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     // weights of the first convolution: lane (row = lane&15, g) holds k = 32 s + 8 g .. + 7 of one output channel; MFMA i
     // takes channel 8 (row>>2) + 4 i + (row&3) on its row, so a lane ends up with the 8 consecutive channels 8 g .. + 7
-    bf16x8 wf[2][KSTEPS0];
+    constexpr int KS0 = RGB ? 2 : KSTEPS0;          // K steps of the first convolution
+    bf16x8 wf[2][KS0];
     const int wrow = 8 * (p16 >> 2) + (p16 & 3);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int s = 0; s < KSTEPS0; ++s)
-            wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w0 + ((size_t)(4 * i + wrow) * (KSTEPS0 * 32) + s * 32 + g * 8) * 2);
-    // the second half of the last K-step is padding ("tap 9"): zero weights there, whatever the packed rows hold, so the
-    // pixel operand of those lanes may be any finite values
-    if (g >= 2) wf[0][KSTEPS0 - 1] = wf[1][KSTEPS0 - 1] = bf16x8{};
+        for (int s = 0; s < KS0; ++s)
+            wf[i][s] = *reinterpret_cast<const bf16x8*>(a.w0 + ((size_t)(4 * i + wrow) * (KS0 * 32) + s * 32 + g * 8) * 2);
+    // K beyond the ninth tap is padding: zero weights there, whatever the packed rows hold, so the pixel operand of those
+    // lanes may be any finite values (Focus: the second half of the last K step; RGB: lane group g of K step s holds
+    // taps 8 s + 2 g and 8 s + 2 g + 1, i.e. everything of step 1 but the first tap of group 0)
+    if constexpr (RGB) {
+        if (g >= 1) wf[0][1] = wf[1][1] = bf16x8{};
+        else
+#pragma unroll
+            for (int e = 4; e < 8; ++e) wf[0][1][e] = wf[1][1][e] = (__bf16)0.f;
+    } else {
+        if (g >= 2) wf[0][KSTEPS0 - 1] = wf[1][KSTEPS0 - 1] = bf16x8{};
+    }
     if constexpr (std::is_same<TX, uint8_t>::value) __syncthreads();   // the table is complete
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int fp = tid + 256 * it;
         if (fp >= F_N) continue;
         if constexpr (RGB) {
-            bf16x8 lo = bf16x8{};
+            bf16x4 lo = bf16x4{};
 #pragma unroll
             for (int c = 0; c < 3; ++c) lo[c] = (__bf16)(float)px1[it][c];
-            *reinterpret_cast<bf16x8*>(lds + fp * F_PITCH) = lo;
-            *reinterpret_cast<bf16x8*>(lds + fp * F_PITCH + 16) = bf16x8{};
+            *reinterpret_cast<bf16x4*>(lds + fp * 8) = lo;
             continue;
         }
         __bf16 ch[12];
@@ -233,18 +243,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         int p = (wave + 4 * t) * 16 + p16;
         p = p < A_N ? p : A_N - 1;
         const int r = p / A_W, c = p - r * A_W;
-        fbase[t] = (r * F_W + c) * F_PITCH + (g & 1) * 16;
+        fbase[t] = RGB ? (r * F_W + c) * 8 : (r * F_W + c) * F_PITCH + (g & 1) * 16;
     }
 #pragma unroll
-    for (int s = 0; s < KSTEPS0; ++s) {
-        const int tap = 2 * s + (g >> 1);           // K-step s covers taps 2 s and 2 s + 1; tap 9 is padding
-        const int tp = tap < 9 ? tap : 0;
-        const int kh = tp / 3, kw = tp - kh * 3;
-        const int toff = (kh * F_W + kw) * F_PITCH;
+    for (int s = 0; s < KS0; ++s) {
         bf16x8 xf[NG];
+        if constexpr (RGB) {
+            // K step s: lane group g holds taps 8 s + 2 g and 8 s + 2 g + 1 (taps beyond the ninth: finite values times zero weights)
+            const int ta = 8 * s + 2 * g, tb = ta + 1;
+            const int pa = ta < 9 ? ta : 0, pb = tb < 9 ? tb : 0;
+            const int offa = ((pa / 3) * F_W + pa % 3) * 8, offb = ((pb / 3) * F_W + pb % 3) * 8;
 #pragma unroll
-        for (int t = 0; t < NG; ++t) {
-            xf[t] = *reinterpret_cast<const bf16x8*>(lds + fbase[t] + toff);   // (tap 9: finite values times zero weights)
+            for (int t = 0; t < NG; ++t) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(lds + fbase[t] + offa);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(lds + fbase[t] + offb);
+                xf[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        } else {
+            const int tap = 2 * s + (g >> 1);           // K-step s covers taps 2 s and 2 s + 1; tap 9 is padding
+            const int tp = tap < 9 ? tap : 0;
+            const int kh = tp / 3, kw = tp - kh * 3;
+            const int toff = (kh * F_W + kw) * F_PITCH;
+#pragma unroll
+            for (int t = 0; t < NG; ++t) {
+                xf[t] = *reinterpret_cast<const bf16x8*>(lds + fbase[t] + toff);   // (tap 9: finite values times zero weights)
+            }
         }
 #pragma unroll
         for (int t = 0; t < NG; ++t)
@@ -373,8 +396,9 @@ int ydet_launch_focus_pair(const ydet_conv_desc* f, const ydet_conv_desc* d, int
     YDET_CHECK_ARG(f->in_dtype == YDET_BF16 && d->in_dtype == YDET_BF16 && d->out_dtype == YDET_BF16, "focus_pair: bf16 weights and output only");
     YDET_CHECK_ARG(f->N > 0 && f->N <= 65535 && f->H > 0 && f->W > 0 && (rgb || (f->H % 2 == 0 && f->W % 2 == 0)),
                    "focus_pair: image %d x %d x %d", f->N, f->H, f->W);
-    YDET_CHECK_ARG(f->Cin == 3 && f->KH == 3 && f->KW == 3 && f->stride == 1 && f->pad == 1 && f->Cout == 32 && f->kp == KSTEPS0 * 32,
-                   "focus_pair: first layer must be Focus + 3x3 / stride 1 / pad 1 with 32 output channels (kp = %d)", KSTEPS0 * 32);
+    YDET_CHECK_ARG(f->Cin == 3 && f->KH == 3 && f->KW == 3 && f->stride == 1 && f->pad == 1 && f->Cout == 32 &&
+                       f->kp == (rgb ? 64 : KSTEPS0 * 32),
+                   "focus_pair: first layer must be [Focus +] 3x3 / stride 1 / pad 1 with 32 output channels (kp = %d)", rgb ? 64 : KSTEPS0 * 32);
     YDET_CHECK_ARG(f->res == nullptr && f->post_scale == nullptr && f->y2 == nullptr && f->pw_w == nullptr,
                    "focus_pair: first layer: no residual / second stage / destination / follower");
     YDET_CHECK_ARG(3LL * f->H * f->W < (1LL << 31), "focus_pair: image of %d x %d pixels", f->H, f->W);

@@ -613,16 +613,7 @@ class Graph:
                 continue
             if rgb and e["act"] != B["act"]:
                 continue
-            if rgb:      # the pair kernel reads 16-channel pixel slots: k = tap * 16 + channel
-                src = e["pc_src"]
-                rows = max(src.cout_pad, 32)
-                w16 = torch.zeros(rows, 10, 16, device=src.w.device, dtype=src.w.dtype)
-                w16[:src.cout_pad, :9, :3] = src.w[:, :9 * src.Cin].reshape(src.cout_pad, 9, src.Cin)[:, :, :3]
-                b16 = torch.zeros(rows, device=src.b.device)
-                b16[:src.cout_pad] = src.b
-                npc = PackedConv(w16.reshape(rows, 160).contiguous(), b16, 16, 32, 3, 3, 160, rows, cin_real=3)
-                self.keep.append(npc)
-                e = dict(e, pc=npc)
+            # (rgb: the pair kernel reads the weights as the stand-alone first-layer kernel does, k = tap * 4 + channel, kp = 64)
             idx = next(i for i, (_, r) in enumerate(self.ops) if r is e0)
             self.ops[idx] = ("focus_pair", dict(focus=e, conv=B, rgb=rgb))
             j = next(i for i, (_, r) in enumerate(self.ops) if r is B)
