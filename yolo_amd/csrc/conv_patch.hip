@@ -16,6 +16,11 @@
 //    conv.hip: swizzled 16-byte chunks, rows permuted so that a lane ends with 16-byte pieces of its pixels' output
 //    rows), software-pipelined like conv.hip's pipelined tile: the fragments of sub-step u + 1 are fetched while the MFMAs
 //    of sub-step u run, one barrier per 64 channels of K.
+//    The A fragments ping-pong between two register sets; the B fragments have one set: fragment j of the next sub-step
+//    is fetched right behind the two MFMAs that consumed fragment j of this one.
+//  * Persistent workgroups, one per CU (the patch and the ring fill its LDS).  Every CU reaches its fill and its epilogue
+//    at about the same time, so whatever a tile needs from memory is requested under the K loop of the tile before: the
+//    next patch and the residual pieces wait in registers, the ring runs on across tile boundaries.
 //  * K order: tap-major, channel-minor -- the order of the tiled kernel, so results equal its results bit for bit.
 #include <stdlib.h>
 
