@@ -141,18 +141,6 @@ def main():
             line += f"  {med:7.1f} {mn:6.1f} {flop / med / 1e6:5.0f}T d{diff:.0e}"
         print(line, flush=True)
         for li, (name, h) in enumerate(libs):
-            if hasattr(h, "ydet_debug_big_trace"):
-                buf = (C.c_ulonglong * 128)()
-                torch.cuda.synchronize()
-                h.ydet_debug_big_trace(buf)
-                names = ["A:reads+issue", "A:lgkm", "A:vmcnt", "A:barrier", "B:mfma", "B:vmcnt", "B:barrier"]
-                print(f"   [{name}] cycles per segment, summed over the K steps of workgroup 0 (wave: " + ", ".join(names) + ")")
-                for w in range(8):
-                    print(f"     wave {w}: " + " ".join(f"{buf[w * 8 + i]:8d}" for i in range(7)) +
-                          "   | since start: loop begins, loop ends, epilogue ends, stores acked (cycles); whole (10 ns ticks): " +
-                          " ".join(f"{buf[64 + w * 8 + i]:7d}" for i in range(5)) +
-                          f" | A split: reads issued {buf[64 + w * 8 + 5]}, refill issued {buf[64 + w * 8 + 6]} | prologue: set-up done {buf[w * 8 + 7] >> 32}, first steps issued {buf[w * 8 + 7] & 0xffffffff}")
-        for li, (name, h) in enumerate(libs):
             if hasattr(h, "ydet_debug_patch_trace"):
                 buf = (C.c_ulonglong * 128)()
                 torch.cuda.synchronize()
