@@ -15,4 +15,5 @@ for m in v2d19 v3spp v4; do
   python3 tools/rocprof_summary.py stats gpurun_out/prof_${tag}_$m/trace/t_kernel_trace.csv > profiles/${tag}_${m}_kernel_stats.csv
 done
 python3 tools/rocprof_summary.py traffic gpurun_out/prof_${tag}_v3spp/fetch/f_counter_collection.csv gpurun_out/prof_${tag}_v3spp/write/w_counter_collection.csv 64 608 > profiles/${tag}_v3spp_pmc_traffic.json
+python3 tools/rocprof_summary.py counters $(find gpurun_out/prof_${tag}_v3spp/mfma_a gpurun_out/prof_${tag}_v3spp/mfma_b -name "*counter_collection.csv" | sort) > profiles/${tag}_v3spp_pmc_mfma.json
 ls -la profiles/ | grep $tag

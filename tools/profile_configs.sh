@@ -16,3 +16,6 @@ out=gpurun_out/prof_${tag}_v3spp
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 tools/bench_configs.py --only v3spp --steps 2 --warmup 1 > $out/fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 tools/bench_configs.py --only v3spp --steps 2 --warmup 1 > $out/write.log 2>&1
 ls $out/trace $out/fetch $out/write
+# MFMA / issue counters of the heaviest configuration (two passes, 8 SQ counters each at most)
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $out/mfma_a -o a -- python3 tools/bench_configs.py --only v3spp --steps 2 --warmup 1 > $out/mfma_a.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/mfma_b -o b -- python3 tools/bench_configs.py --only v3spp --steps 2 --warmup 1 > $out/mfma_b.log 2>&1
