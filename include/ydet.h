@@ -138,6 +138,11 @@ typedef struct {
 int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream);
 /* Bytes of splitk_ws with which ydet_conv2d_nhwc would split this convolution's K; 0: it would not. */
 size_t ydet_conv_splitk_workspace_bytes(const ydet_conv_desc* d);
+/* Which kernel ydet_conv2d_nhwc would launch for this descriptor, as the label the per-kernel timings and the profile
+ * summaries are keyed by ("conv_dma<256x192,bf16->bf16>", "conv_patch<c128>", "conv_pw<k256>", ...), written to out
+ * (n bytes).  Host arithmetic only: nothing is launched and no HIP call is made, so it also answers on a machine without
+ * a GPU (for 256 CUs).  No counterpart in the reference: a diagnostic of this library's dispatch. */
+int ydet_conv_kernel_name(const ydet_conv_desc* d, char* out, int n);
 
 /* Focus + the first convolution, straight from the NCHW image: yolov5_official/modules.py:285-293 (the slicing
  * torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1) followed by Conv) when it is

@@ -500,3 +500,48 @@ def test_kernel_labels_mirror_the_dispatcher(monkeypatch):
     assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<128x128,bf16->bf16>"
     monkeypatch.setenv("YDET_CONV_K8", "0")
     assert lab(256, 512, 3, 3, 1, B, B, M=25600, stride=2) == "conv_dma<128x256,bf16->bf16>"
+
+def test_kernel_label_mirror_equals_library_dispatch():
+    """engine.conv_kernel_label (what bench.py keys its per-kernel times and its `roofline` by) against the library's own
+    answer, ydet_conv_kernel_name -- the dispatch of csrc/conv.hip / conv_pw.hip / conv_patch.hip run dry, host arithmetic
+    only -- over a grid of layer shapes: batch 1 to 64, maps of 13 to 160 pixels, 16 to 1024 channels, 1x1 / 3x3 / stride 2,
+    with and without a residual, the three dtype pairs."""
+    import ctypes as C
+    from yolo_amd import _ffi, engine
+    lib = _ffi.lib()
+
+    def library_label(N, S, cin, cout, k, s, res, in_dt, out_dt):
+        d = _ffi.ConvDesc()
+        p = k // 2
+        Ho = (S + 2 * p - k) // s + 1
+        d.x = d.w = d.bias = d.y = 4096          # (never dereferenced: nothing is launched)
+        d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = N, S, S, cin, cout, k, k, s, p, Ho, Ho
+        vec = 8 if out_dt == _ffi.BF16 else 4
+        bk = 32 if in_dt == _ffi.BF16 else 16
+        d.x_ld, d.y_ld = cin, (cout + vec - 1) // vec * vec
+        d.kp, d.cout_pad = (k * k * cin + bk - 1) // bk * bk, (cout + 127) // 128 * 128
+        d.act, d.in_dtype, d.out_dtype = _ffi.ACT_SILU, in_dt, out_dt
+        if cout % vec:
+            d.cout_store = d.y_ld
+        if res:
+            d.res, d.res_ld, d.res_mode = 4096, d.y_ld, _ffi.RES_AFTER_ACT
+        buf = C.create_string_buffer(96)
+        _ffi.check(lib.ydet_conv_kernel_name(C.byref(d), buf, 96), "ydet_conv_kernel_name")
+        return buf.value.decode(), Ho
+
+    n = 0
+    for N in (1, 32, 64):
+        for S in (13, 19, 20, 38, 40, 76, 80, 152):
+            for cin in (32, 64, 96, 128, 256, 512, 1024):
+                for cout in (32, 64, 75, 128, 200, 256, 512, 1024):
+                    for k, s in ((1, 1), (3, 1), (3, 2)):
+                        for res in (False, True):
+                            for in_dt, out_dt in ((_ffi.BF16, _ffi.BF16), (_ffi.BF16, _ffi.F32), (_ffi.F32, _ffi.F32)):
+                                if N * S * S * max(cin, cout) > 3e8 or (res and (s != 1 or out_dt != in_dt)):
+                                    continue
+                                got, Ho = library_label(N, S, cin, cout, k, s, res, in_dt, out_dt)
+                                want = engine.conv_kernel_label(cin, cout, k, k, k // 2, in_dt, out_dt, M=N * Ho * Ho, stride=s,
+                                                                res=res, geom=(N, S, S))
+                                assert got == want, (N, S, cin, cout, k, s, res, in_dt, out_dt, got, want)
+                                n += 1
+    assert n > 5000

@@ -96,6 +96,7 @@ SYMBOLS = {
     "ydet_abi_version": (C.c_int, []),
     "ydet_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ydet_conv_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "ydet_conv_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_int]),
     "ydet_focus_conv3x3_nchw": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_focus_conv_pair_nchw": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "ydet_rgb_conv3x3_nchw": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),

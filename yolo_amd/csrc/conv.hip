@@ -1024,6 +1024,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a) {
 
 template <typename TIN, typename TOUT>
 int launch_direct(const ConvArgs& a, hipStream_t stream) {
+    if (kernel_probe().on) {
+        snprintf(kernel_probe().name, sizeof(kernel_probe().name), "conv_direct");
+        return YDET_OK;
+    }
     const long long total = a.M * (long long)a.cout_store;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;       // grid-stride beyond 64 workgroups per CU
@@ -1058,13 +1062,17 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
                           (!a.res || (a.res_ld % (16 / (int)sizeof(TIN)) == 0 && a.res_coff % (16 / (int)sizeof(TIN)) == 0)))
                              ? 1
                              : 0;
+        if (a.y2 && !a.lds_epilogue) return fail(YDET_ERR_ARG, "conv: a second destination needs 16-byte aligned output slices");
+        if (kernel_probe().on) {
+            snprintf(kernel_probe().name, sizeof(kernel_probe().name), "conv_dma<%dx%d,%s>", BN, BM, dtype_pair_name<TIN, TOUT>());
+            return YDET_OK;
+        }
         if (lds_dma > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation and device
             static unsigned char optin[kMaxDevices];
             const int rc = raise_dynamic_lds_limit(
                 reinterpret_cast<const void*>(&conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST, PIPE>), (int)lds_dma, optin, "conv");
             if (rc != YDET_OK) return rc;
         }
-        if (a.y2 && !a.lds_epilogue) return fail(YDET_ERR_ARG, "conv: a second destination needs 16-byte aligned output slices");
         hipLaunchKernelGGL((conv_dma_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, false, KCH, NST, PIPE>), dim3((unsigned)nblk),
                            dim3(64 * NW), lds_dma, stream, a, HeadArgs{});
         YDET_CHECK_LAUNCH("conv_dma_kernel");
@@ -1078,6 +1086,11 @@ int launch_tile(const ConvArgs& a0, hipStream_t stream) {
     } else {
         const size_t lds = 2 * (size_t)(BN + BM) * 64;
         const bool is1x1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
+        if (kernel_probe().on) {
+            snprintf(kernel_probe().name, sizeof(kernel_probe().name), "conv_generic<%dx%d,%s,%s>", BN, BM, is1x1 ? "1x1" : "kxk",
+                     dtype_pair_name<TIN, TOUT>());
+            return YDET_OK;
+        }
         if (is1x1)
             hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, BN, BM, WARPS_N, WARPS_M, true>), dim3((unsigned)nblk),
                                dim3(256), lds, stream, a);
@@ -1508,6 +1521,30 @@ int ydet_launch_head_decode(const ydet_conv_desc* d, const ydet_head_desc* hd, h
 extern "C" int ydet_head_conv_decode(const ydet_conv_desc* d, const ydet_head_desc* head, void* stream) {
     clear_error();
     return ydet_launch_head_decode(d, head, as_stream(stream));
+}
+
+namespace ydet {
+namespace conv {
+KernelProbe& kernel_probe() {
+    static thread_local KernelProbe p = {false, {0}};
+    return p;
+}
+}  // namespace conv
+}  // namespace ydet
+
+extern "C" int ydet_conv_kernel_name(const ydet_conv_desc* d, char* out, int n) {
+    clear_error();
+    if (!d || !out || n <= 0) return fail(YDET_ERR_ARG, "conv_kernel_name: null argument");
+    ydet_conv_desc q = *d;
+    q.splitk_ws = nullptr;                  // (a K split launches the same kernel family on partial sums)
+    KernelProbe& p = kernel_probe();
+    p.on = true;
+    p.name[0] = 0;
+    const int rc = ydet_launch_conv(&q, nullptr);
+    p.on = false;
+    if (rc != YDET_OK) return rc;
+    snprintf(out, (size_t)n, "%s", p.name);
+    return YDET_OK;
 }
 
 extern "C" int ydet_conv2d_nhwc(const ydet_conv_desc* d, void* stream) {

@@ -2,6 +2,7 @@
 // image helpers, the MFMA wrappers and the epilogue arithmetic.  gfx950 only.
 #pragma once
 #include <math.h>
+#include <stdio.h>
 
 #include <type_traits>
 
@@ -175,6 +176,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Dry run.  While a thread asks which kernel a descriptor would get (ydet_conv_kernel_name), the launchers write the
+// kernel's label here -- the labels of yolo_amd/engine.py:conv_kernel_label and tools/rocprof_summary.py -- and launch
+// nothing (no HIP call is made: the question can be asked on a machine without a GPU).
+struct KernelProbe {
+    bool on;
+    char name[96];
+};
+KernelProbe& kernel_probe();   // (thread-local; defined in conv.hip)
+template <typename TIN, typename TOUT>
+inline const char* dtype_pair_name() {
+    return sizeof(TIN) == 2 ? (sizeof(TOUT) == 2 ? "bf16->bf16" : "bf16->f32") : "f32->f32";
 }
 
 // The streaming 1x1 kernel of conv_pw.hip (bf16 -> bf16, 128 or 256 input channels, many pixels; bit-identical to the

@@ -448,6 +448,10 @@ bool conv_patch_takes(const ConvArgs& a) {
 int launch_conv_patch(const ConvArgs& a, hipStream_t stream) {
     PatchPlan p;
     if (!plan_patch(a, p)) return fail(YDET_ERR_ARG, "conv_patch: no tile fits this shape");
+    if (kernel_probe().on) {
+        snprintf(kernel_probe().name, sizeof(kernel_probe().name), "conv_patch<c%d>", a.Cin);
+        return YDET_OK;
+    }
     if (a.Cin == 64) return p.fmw == 7 ? launch_patch_t<64, 7>(a, p, stream) : launch_patch_t<64, 5>(a, p, stream);
     return p.fmw == 7 ? launch_patch_t<128, 7>(a, p, stream) : launch_patch_t<128, 5>(a, p, stream);
 }

@@ -240,6 +240,10 @@ bool conv_pw_takes(const ConvArgs& a) {
 }
 
 int launch_conv_pw(const ConvArgs& a, hipStream_t stream) {
+    if (kernel_probe().on) {
+        snprintf(kernel_probe().name, sizeof(kernel_probe().name), "conv_pw<k%d>", a.Cin);
+        return YDET_OK;
+    }
     // Measured on MI355X (YOLOv5s 640 at batch 64, 80x80 and 40x40 maps): with 128 input channels eight waves per
     // workgroup on 16-pixel tiles at four waves per SIMD (125 registers) beat four waves on 32-pixel tiles by 7 %;
     // with 256 the buffers of a 16-pixel tile alone are 64 registers and two waves per SIMD it is.
