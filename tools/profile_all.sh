@@ -1,5 +1,5 @@
 #!/bin/bash
-# Every profile of a round in one go (run through gpurun from the repository root):   tools/profile_all.sh <tag>   e.g. r03
+# Every profile of the current tree in one go (run through gpurun from the repository root):   tools/profile_all.sh <tag>   e.g. r03
 # Headline traces and HBM counters (tools/profile_round.sh), its MFMA / LDS counters (tools/profile_mfma.sh), traces of the
 # other configurations and the HBM counters of the heaviest (tools/profile_configs.sh).  Raw CSVs stay under gpurun_out/;
 # the summaries go to gpurun_out/profiles_<tag>/ -- copy them to profiles/ (tools/profile_collect.sh <tag> does).
