@@ -388,7 +388,12 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if on_gloo else dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    exchange = exchange_leg(m, args, dev, rank, world) if world > 1 else None
+    exchange = None
+    if world > 1:
+        try:      # (outside `value`: a failing collective must not cost the result line)
+            exchange = exchange_leg(m, args, dev, rank, world)
+        except Exception as exc:      # noqa: BLE001
+            exchange = {"error": f"{type(exc).__name__}: {exc}"}
 
     plan, n_ev = m["plan"], m["n_ev"]
     dom_label, dom, roof, stack, kernels, conv_flops = kernel_summary(m, args.compute)
